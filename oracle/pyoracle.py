@@ -1,0 +1,120 @@
+"""ctypes loader for the CPU oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+package (roaringregex_amd/) never does.  See oracle/rr_oracle.h for the parity-pin status.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build(force=False):
+    """Compile liboracle.so (and oracle/_ref when /root/reference is present)."""
+    so = os.path.join(_HERE, "liboracle.so")
+    src = os.path.join(_HERE, "rr_oracle.c")
+    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    ref_so = os.path.join(_HERE, "_ref", "libref_bitset.so")
+    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(ref_so)):
+        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        build()
+        L = C.CDLL(os.path.join(_HERE, "liboracle.so"))
+        L.rro_compile.restype = C.c_void_p
+        L.rro_compile.argtypes = [C.c_char_p, C.c_char_p, C.c_size_t]
+        L.rro_free.argtypes = [C.c_void_p]
+        for f in ("rro_states_n", "rro_initial"):
+            getattr(L, f).restype = C.c_uint32
+            getattr(L, f).argtypes = [C.c_void_p]
+        L.rro_set_class.restype = C.c_int
+        L.rro_set_class.argtypes = [C.c_void_p]
+        L.rro_is_final.restype = C.c_int
+        L.rro_is_final.argtypes = [C.c_void_p, C.c_uint32]
+        L.rro_row.restype = C.c_uint32
+        L.rro_row.argtypes = [C.c_void_p, C.c_uint32, C.c_uint, C.c_int, C.c_void_p, C.c_uint32]
+        L.rro_accepts.restype = C.c_int
+        L.rro_accepts.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
+        L.rro_match_lines.restype = C.c_size_t
+        L.rro_match_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        _LIB = L
+    return _LIB
+
+
+def ref_bitset_lib():
+    """The reference's own BitSet.cc (oracle/_ref/libref_bitset.so), or None when it was never built."""
+    p = os.path.join(_HERE, "_ref", "libref_bitset.so")
+    if not os.path.exists(p):
+        try:
+            build()
+        except Exception:
+            return None
+    if not os.path.exists(p):
+        return None
+    return C.CDLL(p)
+
+
+class OracleError(ValueError):
+    pass
+
+
+class OracleRegex:
+    """Reference semantics of Regex::RRegex (regex.h:212-228) for whole-string acceptance."""
+
+    def __init__(self, pattern):
+        if isinstance(pattern, str):
+            pattern = pattern.encode("latin-1")
+        self.pattern = pattern
+        err = C.create_string_buffer(256)
+        self._h = lib().rro_compile(pattern, err, 256)
+        if not self._h:
+            raise OracleError(err.value.decode())
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            lib().rro_free(self._h)
+            self._h = None
+
+    @property
+    def states_n(self):
+        return lib().rro_states_n(self._h)
+
+    @property
+    def initial(self):
+        return lib().rro_initial(self._h)
+
+    @property
+    def set_class(self):
+        return lib().rro_set_class(self._h)
+
+    def finals(self):
+        return [s for s in range(self.states_n) if lib().rro_is_final(self._h, s)]
+
+    def row(self, state, c, fwd=True):
+        n = self.states_n
+        buf = (C.c_uint32 * max(n, 1))()
+        k = lib().rro_row(self._h, state, c, 1 if fwd else 0, buf, n)
+        return list(buf[:k])
+
+    def accepts(self, s):
+        if isinstance(s, str):
+            s = s.encode("latin-1")
+        return bool(lib().rro_accepts(self._h, s, len(s)))
+
+    def match_lines(self, data):
+        """data: bytes / numpy uint8 array.  Returns numpy uint8 accept vector, one entry per line."""
+        import numpy as np
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+        n = len(a)
+        nl = int((a == 10).sum())
+        nlines = nl + (1 if n and a[-1] != 10 else 0)
+        out = np.zeros(max(nlines, 1), dtype=np.uint8)
+        got = lib().rro_match_lines(self._h, a.ctypes.data if n else None, n, out.ctypes.data, nlines)
+        assert got == nlines, (got, nlines)
+        return out[:nlines]
