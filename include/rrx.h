@@ -1,0 +1,83 @@
+/*
+ * rrx.h — C ABI of the MI355X-native RoaringRegex hot path (librrx.so).
+ *
+ * The reference has no FFI; its only interface is the C++ iterator facade of src/inc/regex.h.  This ABI is
+ * what a binding for that facade binds for the hot path: each entry point names the reference interface it
+ * replaces (paths relative to the reference's src/).  include/rregex.hpp rebuilds the reference's C++ names
+ * (Regex::RRegex, get_acceptance_iter, IteratorWrapper, Match) on top of it; INTEGRATION.md shows the
+ * reference-side stub.
+ *
+ * Conventions: plain pointers and sizes only; no exception crosses the boundary — every function returns
+ * RRX_OK or an error code and rrx_last_error() describes the last failure on the calling thread
+ * (the reference throws std::runtime_error, Parser.cpp:36,155).  "d_" parameters are DEVICE pointers
+ * (hipMalloc'ed on `device`); `stream` is a hipStream_t (NULL = default stream); launches are asynchronous
+ * on that stream.  There is no CPU matcher behind this ABI: matching requires a gfx950 device.
+ */
+#ifndef RRX_H
+#define RRX_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rrx_regex rrx_regex;    /* a compiled pattern: replaces Regex::RRegex, regex.h:212-228        */
+typedef struct rrx_corpus rrx_corpus;  /* a device-resident batch of '\n'-delimited strings + its line index */
+
+enum { RRX_OK = 0, RRX_ERR_PATTERN = 1, RRX_ERR_ARG = 2, RRX_ERR_HIP = 3, RRX_ERR_UNSUPPORTED = 4 };
+
+/* engine selection for rrx_compile_ex */
+enum { RRX_ENGINE_AUTO = 0, RRX_ENGINE_NFA = 1, RRX_ENGINE_DFA = 2 };
+
+/* ---- compile: RRegex::RRegex(const char*), Parser.cpp:161-170 (host only, no device needed) ---------- */
+int rrx_compile(const char *pattern, rrx_regex **out);
+int rrx_compile_ex(const char *pattern, int engine, rrx_regex **out);
+void rrx_free(rrx_regex *re);
+const char *rrx_last_error(void);
+
+/* ---- what the reference would have built (for parity checks on the construction) -------------------- */
+uint32_t rrx_num_states(const rrx_regex *re);      /* states_n, Parser.cpp:163                               */
+int      rrx_set_class(const rrx_regex *re);       /* 1,2,4 = BitSet<W>, 0 = Roaring: Parser.cpp:165-168     */
+uint32_t rrx_ref_initial(const rrx_regex *re);     /* initial_state, regex.h:81                              */
+int      rrx_ref_is_final(const rrx_regex *re, uint32_t state);                 /* final_states, regex.h:177 */
+/* forward row T[idx(state,c,true)] (NFA.cc:9-12) as ascending state numbers; returns its cardinality */
+uint32_t rrx_ref_row(const rrx_regex *re, uint32_t state, unsigned c, uint32_t *out, uint32_t cap);
+
+/* ---- what the device runs ---------------------------------------------------------------------------- */
+int         rrx_engine(const rrx_regex *re);       /* RRX_ENGINE_NFA or RRX_ENGINE_DFA                       */
+const char *rrx_engine_name(const rrx_regex *re);
+uint32_t    rrx_useful_states(const rrx_regex *re);
+uint32_t    rrx_byte_classes(const rrx_regex *re);
+uint32_t    rrx_words_per_set(const rrx_regex *re); /* 32-bit words of the register-resident state set (NFA) */
+/* Serialised device program as 32-bit words (layout: DESIGN.md "Device programs"); returns the word count
+ * (call with cap = 0 to size the buffer).  kind = RRX_ENGINE_NFA / RRX_ENGINE_DFA; 0 if that form was not built. */
+size_t rrx_program_words(const rrx_regex *re, int kind, uint32_t *out, size_t cap);
+
+/* ---- batch of strings: the replacement for calling get_acceptance_iter(line)++ per string ------------ *
+ * regex.h:225-227 + 156-162, for every '\n'-delimited string of a device-resident buffer.  A final fragment
+ * without '\n' is a string too.  Bytes 0x00 and >= 0x80 reject their string (the reference cannot express
+ * the former and has undefined behaviour on the latter, NFA.cc:10,97).                                       */
+int    rrx_corpus_create(int device, const void *d_bytes, size_t nbytes, void *stream, rrx_corpus **out);
+size_t rrx_corpus_num_lines(const rrx_corpus *c);
+size_t rrx_corpus_num_bytes(const rrx_corpus *c);
+void   rrx_corpus_free(rrx_corpus *c);
+/* THE HOT PATH.  d_accept[i] = 1 iff string i is accepted (i.e. *it has a value, regex.h:160-162; its
+ * Match is then [start of string i, its terminator)).  d_accept holds rrx_corpus_num_lines() bytes.          */
+int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint8_t *d_accept, void *stream);
+
+/* explicit extents: item i = d_bytes[d_off[i] .. d_off[i+1] - trim); '\n' is an ordinary character here */
+int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, const uint64_t *d_off, size_t nitems,
+                      uint32_t trim, uint8_t *d_accept, void *stream);
+
+/* ---- host-buffer conveniences (PCIe inclusive; synchronous) ------------------------------------------ */
+/* bytes/accept are HOST pointers; *nlines receives the number of strings; at most cap results are written */
+int rrx_match_host(const rrx_regex *re, int device, const void *bytes, size_t nbytes, uint8_t *accept, size_t cap,
+                   size_t *nlines);
+/* One NUL-terminated host string: `auto it = r.get_acceptance_iter(text)++; *it` (test/main.cpp:25-27).
+ * *accepted = has_value(); *len = strlen(text) = Match.end - Match.start.                                   */
+int rrx_match_cstr(const rrx_regex *re, int device, const char *text, int *accepted, size_t *len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

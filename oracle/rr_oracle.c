@@ -46,7 +46,8 @@ static void set_add(set_t *s, uint32_t x) {
 static void set_or(set_t *d, const set_t *o) {           /* d |= o */
     if (!o->n) return;
     if (d == o) return;
-    uint32_t *m = (uint32_t *)malloc((size_t)(d->n + o->n) * sizeof(uint32_t));
+    const uint32_t room = d->n + o->n;
+    uint32_t *m = (uint32_t *)malloc((size_t)room * sizeof(uint32_t));
     uint32_t i = 0, j = 0, k = 0;
     while (i < d->n && j < o->n) {
         if (d->v[i] < o->v[j]) m[k++] = d->v[i++];
@@ -55,7 +56,7 @@ static void set_or(set_t *d, const set_t *o) {           /* d |= o */
     }
     while (i < d->n) m[k++] = d->v[i++];
     while (j < o->n) m[k++] = o->v[j++];
-    free(d->v); d->v = m; d->n = k; d->cap = d->n + o->n;
+    free(d->v); d->v = m; d->n = k; d->cap = room;
 }
 static void set_assign(set_t *d, const set_t *o) {
     if (d == o) return;

@@ -1,0 +1,272 @@
+"""roaringregex_amd — MI355X-native engine for the RoaringRegex hot path.
+
+Python host layer over the C ABI of librrx.so (include/rrx.h).  It mirrors the reference's interface for the
+path (src/inc/regex.h:100-126, 212-228): RRegex(pattern), RRegex.get_acceptance_iter(text) ->
+IteratorWrapper with advance() (the reference's operator++(int)) and value() (operator*, a Match or None),
+plus the batch entry the reference lacks (Corpus / RRegex.match_corpus).  PyTorch is used only as plumbing
+for device memory and streams.  There is no CPU matcher in this package: if librrx.so is missing the import
+fails loudly, and matching without a gfx950 device raises.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "librrx.so")
+
+ENGINE_AUTO, ENGINE_NFA, ENGINE_DFA = 0, 1, 2
+
+# every symbol include/rrx.h declares (tests check the library exports exactly these)
+ABI_SYMBOLS = (
+    "rrx_compile", "rrx_compile_ex", "rrx_free", "rrx_last_error",
+    "rrx_num_states", "rrx_set_class", "rrx_ref_initial", "rrx_ref_is_final", "rrx_ref_row",
+    "rrx_engine", "rrx_engine_name", "rrx_useful_states", "rrx_byte_classes", "rrx_words_per_set", "rrx_program_words",
+    "rrx_corpus_create", "rrx_corpus_num_lines", "rrx_corpus_num_bytes", "rrx_corpus_free", "rrx_match_corpus",
+    "rrx_match_extents", "rrx_match_host", "rrx_match_cstr",
+)
+
+
+class RRegexError(RuntimeError):
+    """The reference throws std::runtime_error (Parser.cpp:36,155); so do we."""
+
+
+def _load():
+    if not os.path.exists(_SO):
+        raise ImportError(
+            "roaringregex_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % _SO)
+    L = C.CDLL(_SO)
+    vp, u32, sz, i32 = C.c_void_p, C.c_uint32, C.c_size_t, C.c_int
+    sig = {
+        "rrx_compile": (i32, [C.c_char_p, C.POINTER(vp)]),
+        "rrx_compile_ex": (i32, [C.c_char_p, i32, C.POINTER(vp)]),
+        "rrx_free": (None, [vp]),
+        "rrx_last_error": (C.c_char_p, []),
+        "rrx_num_states": (u32, [vp]),
+        "rrx_set_class": (i32, [vp]),
+        "rrx_ref_initial": (u32, [vp]),
+        "rrx_ref_is_final": (i32, [vp, u32]),
+        "rrx_ref_row": (u32, [vp, u32, C.c_uint, vp, u32]),
+        "rrx_engine": (i32, [vp]),
+        "rrx_engine_name": (C.c_char_p, [vp]),
+        "rrx_useful_states": (u32, [vp]),
+        "rrx_byte_classes": (u32, [vp]),
+        "rrx_words_per_set": (u32, [vp]),
+        "rrx_program_words": (sz, [vp, i32, vp, sz]),
+        "rrx_corpus_create": (i32, [i32, vp, sz, vp, C.POINTER(vp)]),
+        "rrx_corpus_num_lines": (sz, [vp]),
+        "rrx_corpus_num_bytes": (sz, [vp]),
+        "rrx_corpus_free": (None, [vp]),
+        "rrx_match_corpus": (i32, [vp, vp, vp, vp]),
+        "rrx_match_extents": (i32, [vp, i32, vp, vp, sz, u32, vp, vp]),
+        "rrx_match_host": (i32, [vp, i32, vp, sz, vp, sz, C.POINTER(sz)]),
+        "rrx_match_cstr": (i32, [vp, i32, C.c_char_p, C.POINTER(i32), C.POINTER(sz)]),
+    }
+    for name, (res, args) in sig.items():
+        f = getattr(L, name)
+        f.restype, f.argtypes = res, args
+    return L
+
+
+_L = _load()
+
+
+def _check(rc):
+    if rc != 0:
+        raise RRegexError(_L.rrx_last_error().decode("latin-1"))
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        import torch
+        stream = torch.cuda.current_stream()
+    return C.c_void_p(stream.cuda_stream)
+
+
+class Match:
+    """regex.h:100-105: [start, end) into the caller's buffer; here as offsets plus the buffer."""
+
+    def __init__(self, buf, start, end):
+        self._buf, self.start, self.end = buf, start, end
+
+    def str(self):
+        return self._buf[self.start:self.end]
+
+
+class IteratorWrapper:
+    """regex.h:113-122 / 150-165.  advance() = operator++(int): consume the whole string (idempotent
+    afterwards); value() = operator*: Match or None.  Before advance() the state set is {initial}."""
+
+    def __init__(self, regex, text, device):
+        self._re, self._text, self._device = regex, text, device
+        self._consumed = False
+        self._accepted = None
+
+    def advance(self):
+        if not self._consumed:
+            acc, n = C.c_int(0), C.c_size_t(0)
+            _check(_L.rrx_match_cstr(self._re._h, self._device, self._text, C.byref(acc), C.byref(n)))
+            self._accepted, self._len = bool(acc.value), n.value
+            self._consumed = True
+        return self
+
+    def value(self):
+        if not self._consumed:
+            # NFA.cc:103-107 on the initial set: only patterns whose initial state is final accept here
+            return Match(self._text, 0, 0) if self._re.accepts_empty else None
+        return Match(self._text, 0, self._len) if self._accepted else None
+
+    def create_copy(self):
+        c = IteratorWrapper(self._re, self._text, self._device)
+        c.__dict__.update(self.__dict__)
+        return c
+
+
+class Corpus:
+    """A device-resident batch of '\\n'-delimited strings plus its per-tile newline index (rrx_corpus)."""
+
+    def __init__(self, data, device=None, stream=None):
+        import torch
+        if isinstance(data, (bytes, bytearray, memoryview)):
+            data = torch.frombuffer(bytearray(data), dtype=torch.uint8) if len(data) else torch.empty(0, dtype=torch.uint8)
+        if not data.is_cuda:
+            dev = torch.device("cuda", 0 if device is None else device)
+            data = data.to(dev)
+        assert data.dtype == torch.uint8 and data.is_contiguous()
+        self.data = data                       # keeps the bytes alive
+        self.device = data.device.index
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(_L.rrx_corpus_create(self.device, C.c_void_p(data.data_ptr() if data.numel() else 0), data.numel(),
+                                        _stream_ptr(stream), C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _L.rrx_corpus_free(self._h)
+            self._h = None
+
+    @property
+    def num_lines(self):
+        return _L.rrx_corpus_num_lines(self._h)
+
+    @property
+    def num_bytes(self):
+        return _L.rrx_corpus_num_bytes(self._h)
+
+
+class RRegex:
+    """regex.h:212-228.  RRegex(pattern) compiles on the host (Parser.cpp:161-170)."""
+
+    def __init__(self, pattern, engine=ENGINE_AUTO, device=0):
+        if isinstance(pattern, str):
+            pattern = pattern.encode("latin-1")
+        self.pattern = pattern
+        self.device = device
+        self._h = C.c_void_p()
+        _check(_L.rrx_compile_ex(pattern, engine, C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _L.rrx_free(self._h)
+            self._h = None
+
+    # ---- the reference's interface for this path
+    def get_acceptance_iter(self, text):
+        if isinstance(text, str):
+            text = text.encode("latin-1")
+        return IteratorWrapper(self, text, self.device)
+
+    # ---- batch entry
+    def match_corpus(self, corpus, out=None, stream=None):
+        """accept[i] = 1 iff line i of the corpus is accepted.  Asynchronous on `stream`."""
+        import torch
+        n = corpus.num_lines
+        if out is None:
+            out = torch.empty(n, dtype=torch.uint8, device=corpus.data.device)
+        assert out.is_cuda and out.dtype == torch.uint8 and out.numel() >= n
+        with torch.cuda.device(corpus.device):
+            _check(_L.rrx_match_corpus(self._h, corpus._h, C.c_void_p(out.data_ptr() if n else 0), _stream_ptr(stream)))
+        return out[:n]
+
+    def match_extents(self, data, offsets, trim=0, out=None, stream=None):
+        """item i = data[offsets[i] : offsets[i+1] - trim]; '\\n' is an ordinary character."""
+        import torch
+        n = offsets.numel() - 1
+        assert data.is_cuda and offsets.is_cuda and offsets.dtype in (torch.int64, torch.uint64)
+        if out is None:
+            out = torch.empty(n, dtype=torch.uint8, device=data.device)
+        with torch.cuda.device(data.device.index):
+            _check(_L.rrx_match_extents(self._h, data.device.index, C.c_void_p(data.data_ptr() if data.numel() else 0),
+                                        C.c_void_p(offsets.data_ptr()), n, trim, C.c_void_p(out.data_ptr() if n else 0),
+                                        _stream_ptr(stream)))
+        return out[:n]
+
+    def match_host(self, data):
+        """Host bytes in, numpy accept vector out (upload + index + match + download; synchronous)."""
+        import numpy as np
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+        cap = int((a == 10).sum()) + 1
+        out = np.zeros(cap, dtype=np.uint8)
+        n = C.c_size_t(0)
+        _check(_L.rrx_match_host(self._h, self.device, C.c_void_p(a.ctypes.data if len(a) else 0), len(a),
+                                 C.c_void_p(out.ctypes.data), cap, C.byref(n)))
+        return out[:n.value]
+
+    # ---- introspection (parity checks on the construction; see include/rrx.h)
+    @property
+    def states_n(self):
+        return _L.rrx_num_states(self._h)
+
+    @property
+    def set_class(self):
+        return _L.rrx_set_class(self._h)
+
+    @property
+    def initial(self):
+        return _L.rrx_ref_initial(self._h)
+
+    def finals(self):
+        return [s for s in range(self.states_n) if _L.rrx_ref_is_final(self._h, s)]
+
+    def row(self, state, c):
+        n = self.states_n
+        buf = (C.c_uint32 * max(n, 1))()
+        k = _L.rrx_ref_row(self._h, state, c, buf, n)
+        return list(buf[:k])
+
+    @property
+    def engine(self):
+        return _L.rrx_engine(self._h)
+
+    @property
+    def engine_name(self):
+        return _L.rrx_engine_name(self._h).decode()
+
+    @property
+    def useful_states(self):
+        return _L.rrx_useful_states(self._h)
+
+    @property
+    def byte_classes(self):
+        return _L.rrx_byte_classes(self._h)
+
+    @property
+    def words_per_set(self):
+        return _L.rrx_words_per_set(self._h)
+
+    def program(self, kind):
+        """Serialised device program (numpy uint32), or None if that form was not built."""
+        import numpy as np
+        n = _L.rrx_program_words(self._h, kind, None, 0)
+        if not n:
+            return None
+        out = np.zeros(n, dtype=np.uint32)
+        _L.rrx_program_words(self._h, kind, C.c_void_p(out.ctypes.data), n)
+        return out
+
+    @property
+    def accepts_empty(self):
+        for kind in (ENGINE_NFA, ENGINE_DFA):
+            p = self.program(kind)
+            if p is not None:
+                return bool(p[3])
+        return False

@@ -1,0 +1,295 @@
+// abi.cpp — the C ABI of librrx.so (include/rrx.h): host compile pipeline + device program upload + launches.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/rrx.h"
+#include "device.hpp"
+#include "frontend.hpp"
+#include "lower.hpp"
+
+using namespace rrx;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+int hip_fail(hipError_t e, const char *what) {
+    return fail(RRX_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIP_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return hip_fail(e_, #expr); } while (0)
+
+constexpr uint32_t kMaxSubsetStates = 16384;   // subset construction is abandoned beyond this
+
+struct DeviceTables {
+    void *blob = nullptr;
+    dev::NfaDevice nfa;
+    dev::DfaDevice dfa;
+};
+
+int instantiated_width(uint32_t W) { return W <= 4 ? (int)W : W <= 6 ? 6 : 8; }
+
+}  // namespace
+
+struct rrx_regex {
+    std::string pattern;
+    RefAutomaton ref;
+    Trimmed trimmed;
+    bool has_nfa = false, has_dfa = false;
+    NfaProgram nfa;
+    DfaProgram dfa;
+    int engine = 0;
+    mutable std::mutex mu;
+    mutable std::map<int, DeviceTables> on_device;
+
+    ~rrx_regex() {
+        for (auto &kv : on_device) if (kv.second.blob) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.blob); }
+    }
+
+    // Upload the program for `device` once; returns the device-side descriptors.
+    int tables(int device, const DeviceTables **out) const {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = on_device.find(device);
+        if (it != on_device.end()) { *out = &it->second; return RRX_OK; }
+        HIP_TRY(hipSetDevice(device));
+        DeviceTables t;
+        std::vector<uint8_t> host;
+        auto put = [&](const void *p, size_t n) { size_t off = (host.size() + 15) & ~(size_t)15; host.resize(off + n); std::memcpy(host.data() + off, p, n); return off; };
+        size_t oB = 0, oX = 0, oC = 0, oN = 0, oA = 0;
+        if (engine == RRX_ENGINE_NFA) {
+            const uint32_t W = nfa.W, WP = (uint32_t)instantiated_width(W);
+            std::vector<uint32_t> B((size_t)256 * WP, 0), X((size_t)nfa.nbits * WP, 0);
+            for (uint32_t c = 0; c < 256; c++) for (uint32_t w = 0; w < W; w++) B[(size_t)c * WP + w] = nfa.B[(size_t)c * W + w];
+            for (uint32_t b = 0; b < nfa.nbits; b++) for (uint32_t w = 0; w < W; w++) X[(size_t)b * WP + w] = nfa.X[(size_t)b * W + w];
+            oB = put(B.data(), B.size() * 4);
+            oX = put(X.data(), X.size() * 4);
+            t.nfa.W = WP; t.nfa.nbits = nfa.nbits; t.nfa.any_exc = nfa.n_exc ? 1 : 0;
+            std::memset(&t.nfa.masks, 0, sizeof t.nfa.masks);
+            for (uint32_t w = 0; w < W; w++) {
+                t.nfa.masks.init[w] = nfa.init[w]; t.nfa.masks.fin[w] = nfa.fin[w]; t.nfa.masks.chain[w] = nfa.chain[w];
+                t.nfa.masks.self[w] = nfa.self[w]; t.nfa.masks.excm[w] = nfa.excm[w];
+            }
+        } else {
+            oC = put(dfa.cls, 256);
+            oN = put(dfa.next.data(), dfa.next.size() * 2);
+            oA = put(dfa.accepting.data(), dfa.accepting.size());
+            t.dfa.nstates = dfa.nstates; t.dfa.ncls = dfa.ncls; t.dfa.start = dfa.start;
+        }
+        HIP_TRY(hipMalloc(&t.blob, host.size() + 16));
+        HIP_TRY(hipMemcpy(t.blob, host.data(), host.size(), hipMemcpyHostToDevice));
+        const uint8_t *base = static_cast<const uint8_t *>(t.blob);
+        if (engine == RRX_ENGINE_NFA) {
+            t.nfa.B = reinterpret_cast<const uint32_t *>(base + oB);
+            t.nfa.X = reinterpret_cast<const uint32_t *>(base + oX);
+        } else {
+            t.dfa.cls = base + oC;
+            t.dfa.next = reinterpret_cast<const uint16_t *>(base + oN);
+            t.dfa.acc = base + oA;
+        }
+        auto ins = on_device.emplace(device, t);
+        *out = &ins.first->second;
+        return RRX_OK;
+    }
+};
+
+struct rrx_corpus {
+    int device = 0;
+    const uint8_t *d_bytes = nullptr;
+    size_t nbytes = 0, ntiles = 0, nlines = 0;
+    uint32_t *d_counts = nullptr;
+    uint64_t *d_base = nullptr;
+};
+
+extern "C" {
+
+const char *rrx_last_error(void) { return g_err.c_str(); }
+
+int rrx_compile_ex(const char *pattern, int engine, rrx_regex **out) {
+    if (!pattern || !out) return fail(RRX_ERR_ARG, "null argument");
+    if (engine < RRX_ENGINE_AUTO || engine > RRX_ENGINE_DFA) return fail(RRX_ERR_ARG, "unknown engine");
+    *out = nullptr;
+    rrx_regex *re = new rrx_regex();
+    try {
+        re->pattern = pattern;
+        re->ref = build_reference_automaton(re->pattern);
+        re->trimmed = trim(re->ref);
+        if (engine != RRX_ENGINE_DFA) re->has_nfa = lower_nfa(re->trimmed, dev::kMaxNfaWords * 32, re->nfa);
+        if (engine != RRX_ENGINE_NFA) {
+            re->has_dfa = lower_dfa(re->trimmed, kMaxSubsetStates, re->dfa);
+            if (re->has_dfa && (size_t)re->dfa.nstates * re->dfa.ncls * 2 > dev::kDfaLdsBudget) re->has_dfa = false;
+        }
+    } catch (const PatternError &e) {
+        delete re;
+        return fail(RRX_ERR_PATTERN, e.what());
+    } catch (const std::exception &e) {
+        delete re;
+        return fail(RRX_ERR_PATTERN, std::string("internal: ") + e.what());
+    }
+    if (engine == RRX_ENGINE_NFA) re->engine = re->has_nfa ? RRX_ENGINE_NFA : 0;
+    else if (engine == RRX_ENGINE_DFA) re->engine = re->has_dfa ? RRX_ENGINE_DFA : 0;
+    else re->engine = re->has_dfa ? RRX_ENGINE_DFA : re->has_nfa ? RRX_ENGINE_NFA : 0;
+    if (!re->engine) {
+        char msg[200];
+        std::snprintf(msg, sizeof msg, "automaton too large for the requested engine (%u useful states)", re->trimmed.n);
+        delete re;
+        return fail(RRX_ERR_UNSUPPORTED, msg);
+    }
+    *out = re;
+    return RRX_OK;
+}
+int rrx_compile(const char *pattern, rrx_regex **out) { return rrx_compile_ex(pattern, RRX_ENGINE_AUTO, out); }
+void rrx_free(rrx_regex *re) { delete re; }
+
+uint32_t rrx_num_states(const rrx_regex *re) { return re->ref.states_n; }
+int rrx_set_class(const rrx_regex *re) { return re->ref.set_class(); }
+uint32_t rrx_ref_initial(const rrx_regex *re) { return re->ref.initial; }
+int rrx_ref_is_final(const rrx_regex *re, uint32_t s) { return s < re->ref.states_n && re->ref.is_final[s]; }
+uint32_t rrx_ref_row(const rrx_regex *re, uint32_t state, unsigned c, uint32_t *out, uint32_t cap) {
+    std::vector<uint32_t> r = re->ref.row(state, c);
+    for (size_t i = 0; i < r.size() && i < cap; i++) out[i] = r[i];
+    return (uint32_t)r.size();
+}
+int rrx_engine(const rrx_regex *re) { return re->engine; }
+const char *rrx_engine_name(const rrx_regex *re) { return re->engine == RRX_ENGINE_DFA ? "dfa-table" : "nfa-shift-and"; }
+uint32_t rrx_useful_states(const rrx_regex *re) { return re->trimmed.n; }
+uint32_t rrx_byte_classes(const rrx_regex *re) { return re->trimmed.ncls; }
+uint32_t rrx_words_per_set(const rrx_regex *re) { return re->has_nfa ? re->nfa.W : 0; }
+
+size_t rrx_program_words(const rrx_regex *re, int kind, uint32_t *out, size_t cap) {
+    std::vector<uint32_t> w;
+    if (kind == RRX_ENGINE_NFA && re->has_nfa) {
+        const NfaProgram &p = re->nfa;
+        w = {p.W, p.nbits, p.n_exc, p.accepts_empty ? 1u : 0u};
+        for (auto *v : {&p.init, &p.fin, &p.chain, &p.self, &p.excm, &p.B, &p.X}) w.insert(w.end(), v->begin(), v->end());
+    } else if (kind == RRX_ENGINE_DFA && re->has_dfa) {
+        const DfaProgram &d = re->dfa;
+        w = {d.nstates, d.ncls, d.start, d.accepts_empty ? 1u : 0u};
+        for (int c = 0; c < 256; c++) w.push_back(d.cls[c]);
+        for (uint8_t a : d.accepting) w.push_back(a);
+        for (uint16_t n : d.next) w.push_back(n);
+    }
+    for (size_t i = 0; i < w.size() && i < cap; i++) out[i] = w[i];
+    return w.size();
+}
+
+int rrx_corpus_create(int device, const void *d_bytes, size_t nbytes, void *stream, rrx_corpus **out) {
+    if (!out || (nbytes && !d_bytes)) return fail(RRX_ERR_ARG, "null argument");
+    if (reinterpret_cast<uintptr_t>(d_bytes) & 15) return fail(RRX_ERR_ARG, "corpus base must be 16-byte aligned");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(device));
+    rrx_corpus *c = new rrx_corpus();
+    c->device = device;
+    c->d_bytes = static_cast<const uint8_t *>(d_bytes);
+    c->nbytes = nbytes;
+    c->ntiles = (nbytes + dev::kTile - 1) / dev::kTile;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->d_counts), (c->ntiles + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_base), (c->ntiles + 1) * sizeof(uint64_t));
+    if (e != hipSuccess) { rrx_corpus_free(c); return hip_fail(e, "hipMalloc(line index)"); }
+    int rc = dev::count_newlines_per_tile(c->d_bytes, nbytes, c->d_counts, c->ntiles, stream);
+    if (!rc) rc = dev::scan_tile_counts(c->d_counts, c->d_base, c->ntiles, stream);
+    if (rc) { rrx_corpus_free(c); return hip_fail((hipError_t)rc, "line index launch"); }
+    uint64_t total = 0;
+    uint8_t last = '\n';
+    e = hipMemcpyAsync(&total, c->d_base + c->ntiles, sizeof total, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess && nbytes) e = hipMemcpyAsync(&last, c->d_bytes + nbytes - 1, 1, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    if (e != hipSuccess) { rrx_corpus_free(c); return hip_fail(e, "line index readback"); }
+    c->nlines = (size_t)total + ((nbytes && last != '\n') ? 1 : 0);
+    *out = c;
+    return RRX_OK;
+}
+size_t rrx_corpus_num_lines(const rrx_corpus *c) { return c->nlines; }
+size_t rrx_corpus_num_bytes(const rrx_corpus *c) { return c->nbytes; }
+void rrx_corpus_free(rrx_corpus *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->d_counts) (void)hipFree(c->d_counts);
+    if (c->d_base) (void)hipFree(c->d_base);
+    delete c;
+}
+
+int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint8_t *d_accept, void *stream) {
+    if (!re || !c || (c->nlines && !d_accept)) return fail(RRX_ERR_ARG, "null argument");
+    const DeviceTables *t;
+    int rc = re->tables(c->device, &t);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    int e = re->engine == RRX_ENGINE_NFA
+                ? dev::match_tiles_nfa(t->nfa, c->d_bytes, c->nbytes, c->d_base, c->ntiles, d_accept, stream)
+                : dev::match_tiles_dfa(t->dfa, c->d_bytes, c->nbytes, c->d_base, c->ntiles, d_accept, stream);
+    if (e) return hip_fail((hipError_t)e, "match_tiles launch");
+    return RRX_OK;
+}
+
+int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, const uint64_t *d_off, size_t nitems, uint32_t trim,
+                      uint8_t *d_accept, void *stream) {
+    if (!re || (nitems && (!d_off || !d_accept))) return fail(RRX_ERR_ARG, "null argument");
+    const DeviceTables *t;
+    int rc = re->tables(device, &t);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    const uint8_t *b = static_cast<const uint8_t *>(d_bytes);
+    int e = re->engine == RRX_ENGINE_NFA ? dev::match_extents_nfa(t->nfa, b, d_off, nitems, trim, d_accept, stream)
+                                         : dev::match_extents_dfa(t->dfa, b, d_off, nitems, trim, d_accept, stream);
+    if (e) return hip_fail((hipError_t)e, "match_extents launch");
+    return RRX_OK;
+}
+
+int rrx_match_host(const rrx_regex *re, int device, const void *bytes, size_t nbytes, uint8_t *accept, size_t cap, size_t *nlines) {
+    if (!re || (nbytes && !bytes) || !nlines) return fail(RRX_ERR_ARG, "null argument");
+    HIP_TRY(hipSetDevice(device));
+    void *d_bytes = nullptr;
+    uint8_t *d_acc = nullptr;
+    rrx_corpus *c = nullptr;
+    int rc = RRX_OK;
+    hipError_t e = hipMalloc(&d_bytes, nbytes + 16);
+    if (e == hipSuccess && nbytes) e = hipMemcpy(d_bytes, bytes, nbytes, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = hip_fail(e, "corpus upload");
+    if (!rc) rc = rrx_corpus_create(device, d_bytes, nbytes, nullptr, &c);
+    if (!rc) {
+        *nlines = c->nlines;
+        e = hipMalloc(reinterpret_cast<void **>(&d_acc), c->nlines + 16);
+        if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(accept)");
+    }
+    if (!rc) rc = rrx_match_corpus(re, c, d_acc, nullptr);
+    if (!rc) {
+        size_t n = c->nlines < cap ? c->nlines : cap;
+        e = hipMemcpy(accept, d_acc, n, hipMemcpyDeviceToHost);    // synchronises with the default stream
+        if (e != hipSuccess) rc = hip_fail(e, "accept readback");
+    }
+    if (c) rrx_corpus_free(c);
+    if (d_acc) (void)hipFree(d_acc);
+    if (d_bytes) (void)hipFree(d_bytes);
+    return rc;
+}
+
+int rrx_match_cstr(const rrx_regex *re, int device, const char *text, int *accepted, size_t *len) {
+    if (!re || !text || !accepted) return fail(RRX_ERR_ARG, "null argument");
+    const size_t n = std::strlen(text);                       // regex.h:157: consume up to the terminator
+    if (len) *len = n;
+    HIP_TRY(hipSetDevice(device));
+    uint8_t *d = nullptr;
+    const size_t off_at = (n + 15) & ~(size_t)15;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d), off_at + 32);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(text)");
+    uint64_t off[2] = {0, n};
+    int rc = RRX_OK;
+    if (n) e = hipMemcpy(d, text, n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(d + off_at, off, sizeof off, hipMemcpyHostToDevice);
+    if (e != hipSuccess) rc = hip_fail(e, "text upload");
+    uint8_t *d_acc = d + off_at + 16;
+    if (!rc) rc = rrx_match_extents(re, device, d, reinterpret_cast<const uint64_t *>(d + off_at), 1, 0, d_acc, nullptr);
+    uint8_t a = 0;
+    if (!rc) { e = hipMemcpy(&a, d_acc, 1, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hip_fail(e, "accept readback"); }
+    (void)hipFree(d);
+    *accepted = a;
+    return rc;
+}
+
+}  // extern "C"

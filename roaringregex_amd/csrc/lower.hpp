@@ -1,0 +1,67 @@
+// lower.hpp — language-preserving lowering of the reference-numbered automaton into device programs.
+//
+// The reference steps `next = OR over s in current of T[c][s]` (NFA.cc:86-100): one row-OR per live
+// state per byte.  On a 64-wide SIMD that formulation diverges per lane, so the host rewrites the SAME
+// automaton into forms whose per-byte cost does not depend on the live set:
+//
+//   NfaProgram  "shift-and with exceptions": states are split by in-label so that every state is entered
+//               on one character set (B[c] = states enterable on c); the states are laid out along a
+//               maximum path cover so that most edges are "next bit" edges.  One step is
+//                   next = ( ((S << 1) & CHAIN) | (S & SELF) | OR_{e in S & EXC} X[e] ) & B[c]
+//               and replaces NFA.cc:86-100 (BitSet classes) and NFA.cc:77-85 (Roaring class) alike.
+//   DfaProgram  the reachable state SETS of the reference's loop interned to small integers on the host
+//               (subset construction + minimisation): one table lookup per byte.  Used when it stays small.
+//
+// Every rewrite here (trim, NUL removal, in-label split, bisimulation quotients, subset construction) keeps
+// the accepted language of the reference automaton; tests/test_lowering.py replays the programs on the CPU
+// and compares with the oracle.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "frontend.hpp"
+
+namespace rrx {
+
+// Useful part (reachable from initial AND able to reach a final state) of the reference automaton.
+struct Trimmed {
+    uint32_t n = 0;                         // 0 => empty language
+    uint32_t initial = 0;
+    std::vector<uint8_t> is_final;
+    std::vector<std::vector<Edge>> out;     // labels never contain NUL (it cannot occur inside a string)
+    std::vector<uint32_t> ref_id;           // state id in the reference numbering
+    uint32_t ncls = 1;                      // byte classes; class 0 = bytes on which nothing moves
+    uint8_t cls[256];                       // byte -> class (0x00 and >= 0x80 are class 0)
+    std::vector<uint8_t> cls_rep;           // one representative byte per class (cls_rep[0] unused)
+};
+
+Trimmed trim(const RefAutomaton &a);
+
+struct NfaProgram {
+    uint32_t W = 0;                         // 32-bit words per state set
+    uint32_t nbits = 0;                     // positions in use
+    uint32_t n_exc = 0;                     // positions with an exception row
+    uint32_t max_exc_row_words = 0;
+    std::vector<uint32_t> init, fin, chain, self, excm;   // W words each
+    std::vector<uint32_t> X;                // nbits rows of W words: extra successors of position p
+    std::vector<uint32_t> B;                // 256 rows of W words: positions enterable on byte c
+    bool accepts_empty = false;
+};
+
+struct DfaProgram {
+    uint32_t nstates = 0;                   // including the dead state (id 0)
+    uint32_t ncls = 0;                      // = Trimmed::ncls
+    uint32_t start = 0;
+    std::vector<uint8_t> accepting;         // per state
+    std::vector<uint16_t> next;             // [state][class]
+    uint8_t cls[256];
+    bool accepts_empty = false;
+};
+
+// Returns false if the node count exceeds max_bits.
+bool lower_nfa(const Trimmed &t, uint32_t max_bits, NfaProgram &out);
+// Returns false if subset construction exceeds max_states.
+bool lower_dfa(const Trimmed &t, uint32_t max_states, DfaProgram &out);
+
+}  // namespace rrx

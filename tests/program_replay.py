@@ -1,0 +1,54 @@
+"""Test-side interpreters of the serialised device programs (rrx_program_words; layout in DESIGN.md
+"Device programs").  They restate what kernels.hip's engines do per byte, in numpy/python ints, so that the
+host lowering can be checked against the oracle on the CPU.  Test infrastructure only."""
+import numpy as np
+
+
+class NfaReplay:
+    def __init__(self, words):
+        w = [int(x) for x in words]
+        self.W, self.nbits, self.n_exc, self.accepts_empty = w[0], w[1], w[2], bool(w[3])
+        W, o = self.W, 4
+
+        def big(ws):
+            v = 0
+            for i, x in enumerate(ws):
+                v |= x << (32 * i)
+            return v
+        self.init, self.fin, self.chain, self.self_, self.excm = [big(w[o + i * W:o + (i + 1) * W]) for i in range(5)]
+        o += 5 * W
+        self.B = [big(w[o + c * W:o + (c + 1) * W]) for c in range(256)]
+        o += 256 * W
+        self.X = [big(w[o + b * W:o + (b + 1) * W]) for b in range(self.nbits)]
+        self.mask = (1 << (32 * W)) - 1
+
+    def accepts(self, s):
+        S = self.init
+        for c in s:
+            if c == 0 or c >= 0x80:
+                return False
+            t = ((S << 1) & self.mask & self.chain) | (S & self.self_)
+            e = S & self.excm
+            while e:
+                b = (e & -e).bit_length() - 1
+                e &= e - 1
+                t |= self.X[b]
+            S = t & self.B[c]
+        return (S & self.fin) != 0
+
+
+class DfaReplay:
+    def __init__(self, words):
+        w = np.asarray(words, dtype=np.int64)
+        self.nstates, self.ncls, self.start, self.accepts_empty = int(w[0]), int(w[1]), int(w[2]), bool(w[3])
+        self.cls = w[4:260]
+        self.acc = w[260:260 + self.nstates]
+        self.next = w[260 + self.nstates:].reshape(self.nstates, self.ncls)
+
+    def accepts(self, s):
+        st = self.start
+        for c in s:
+            if c == 0 or c >= 0x80:
+                return False
+            st = int(self.next[st, self.cls[c]])
+        return bool(self.acc[st])

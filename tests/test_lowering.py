@@ -1,0 +1,147 @@
+"""Host logic on the CPU: the product front end must build the reference's table exactly (checked against the
+oracle row by row), and both device programs must keep its language (replayed in Python).  No GPU needed."""
+import random
+
+import pytest
+
+import roaringregex_amd as rr
+from patterns import EMAIL, K1000, K1000_CONTAINS, KAT, U2, random_pattern, strings_near
+from program_replay import DfaReplay, NfaReplay
+from pyoracle import OracleError, OracleRegex
+
+
+def _same_table(o, r, sample=None):
+    assert (o.states_n, o.initial, o.set_class) == (r.states_n, r.initial, r.set_class)
+    assert o.finals() == r.finals()
+    states = range(o.states_n) if sample is None else sample
+    for s in states:
+        for c in range(128):
+            assert o.row(s, c) == r.row(s, c), (s, c)
+
+
+def test_front_end_builds_the_reference_table_kat():
+    for k in KAT["kat"]:
+        _same_table(OracleRegex(k["pattern"]), rr.RRegex(k["pattern"]))
+
+
+def test_front_end_builds_the_reference_table_big():
+    rng = random.Random(5)
+    for k in KAT["big_states"]:
+        o = OracleRegex(k["pattern"])
+        r = rr.RRegex(k["pattern"])
+        assert r.states_n == k["states_n"] and r.set_class == 0
+        _same_table(o, r, sample=[0, 1, 2, o.states_n - 1] + [rng.randrange(o.states_n) for _ in range(40)])
+
+
+def test_front_end_random_patterns_match_oracle_tables():
+    rng = random.Random(11)
+    n_ok = 0
+    for _ in range(300):
+        p = random_pattern(rng)
+        try:
+            o = OracleRegex(p)
+        except OracleError:
+            with pytest.raises(rr.RRegexError):
+                rr.RRegex(p)
+            continue
+        if o.states_n > 400:
+            continue
+        try:
+            r = rr.RRegex(p)
+        except rr.RRegexError as e:
+            assert "too large" in str(e), (p, e)
+            continue
+        _same_table(o, r)
+        n_ok += 1
+    assert n_ok > 150
+
+
+@pytest.mark.parametrize("p", ["a)", "|a", "a|", "()", "*a", "?", "+", "a{2", "[", "a{", "caf\xe9", "(|a)", "a(|b)"])
+def test_errors_match_oracle(p):
+    with pytest.raises(OracleError):
+        OracleRegex(p)
+    with pytest.raises(rr.RRegexError):
+        rr.RRegex(p)
+
+
+def test_error_messages_of_the_reference_are_kept():
+    # Parser.cpp:36 and Parser.cpp:155
+    with pytest.raises(rr.RRegexError, match="invalid expression!"):
+        rr.RRegex("[")
+    with pytest.raises(rr.RRegexError, match="invalid expression"):
+        rr.RRegex("a)")
+
+
+def _replays(r):
+    out = []
+    for kind, cls in ((rr.ENGINE_NFA, NfaReplay), (rr.ENGINE_DFA, DfaReplay)):
+        w = r.program(kind)
+        if w is not None:
+            out.append(cls(w))
+    assert out
+    return out
+
+
+def test_programs_keep_the_language_kat():
+    for k in KAT["kat"]:
+        r = rr.RRegex(k["pattern"])
+        for rep in _replays(r):
+            for t in k["accepts"]:
+                assert rep.accepts(t.encode("latin-1")), (k["pattern"], t, type(rep).__name__)
+            for t in k["rejects"]:
+                assert not rep.accepts(t.encode("latin-1")), (k["pattern"], t, type(rep).__name__)
+
+
+def test_programs_keep_the_language_random():
+    rng = random.Random(23)
+    checked = 0
+    for _ in range(250):
+        p = random_pattern(rng)
+        try:
+            o = OracleRegex(p)
+        except OracleError:
+            continue
+        if o.states_n > 300:
+            continue
+        try:
+            r = rr.RRegex(p)
+        except rr.RRegexError:
+            continue
+        reps = _replays(r)
+        for t in strings_near(rng, o):
+            want = o.accepts(t)
+            for rep in reps:
+                assert rep.accepts(t.encode()) == want, (p, t, type(rep).__name__)
+            checked += 1
+    assert checked > 5000
+
+
+def test_programs_keep_the_language_configs():
+    rng = random.Random(3)
+    cases = {
+        EMAIL: ["john.doe_1@mail.example.com", "john@", "@x", "a@b c", "a@b", "a.b@c.d.e", "@", "a@@b", ""],
+        U2: ["https://www.example.com:8080/a/b/c.html?x=1&y=2#frag", "http://example.com", "http://example",
+             "gopher://example.com/", "ftp://a.bc", "ftp://a.b", "http://a-b.c-d.ef:1/x//y?#", "https://a.b.c.d.ef",
+             "http://abcdefghijklmnopq.com", "http://abcdefghijklmnop.com", "http://x.com:123456", ""],
+        "a{1,300}": ["", "a", "a" * 299, "a" * 300, "a" * 301, "a" * 400, "a" * 150 + "b"],
+        K1000: ["k1", "k1000", "k1001", "k0", "k999", "k", "k01", "k100", "kk1", "k10 ", ""],
+        K1000_CONTAINS: ["GET /index k17 200", "xk1", "k", "no keyword here", "k0 k", "zzk1000zz", ""],
+    }
+    for p, texts in cases.items():
+        o = OracleRegex(p)
+        r = rr.RRegex(p)
+        for rep in _replays(r):
+            for t in texts:
+                assert rep.accepts(t.encode()) == o.accepts(t), (p[:30], t, type(rep).__name__)
+
+
+def test_reduction_statistics():
+    # what the compaction buys on the BASELINE configs (documented in DESIGN.md)
+    r = rr.RRegex(U2)
+    assert r.states_n == 226 and r.useful_states == 83 and r.byte_classes == 16
+    assert r.words_per_set == 3
+    r = rr.RRegex("a{1,85}", rr.ENGINE_NFA)
+    w = r.program(rr.ENGINE_NFA)
+    assert w[1] == 86 and w[2] == 0           # a pure shift chain: no exception rows
+    r = rr.RRegex(K1000)
+    assert r.states_n == 7786 and r.engine == rr.ENGINE_DFA
