@@ -34,6 +34,13 @@ def _load():
         raise ImportError(
             "roaringregex_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % _SO)
+    # librrx.so needs libamdhip64.so.7.  PyTorch-ROCm ships its own copy under the same SONAME and the dynamic
+    # loader keeps whichever is loaded first, so import torch first: one HIP runtime per process, the one that
+    # owns the tensors we are handed.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(_SO)
     vp, u32, sz, i32 = C.c_void_p, C.c_uint32, C.c_size_t, C.c_int
     sig = {

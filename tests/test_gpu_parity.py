@@ -1,0 +1,228 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle, bit-exact on the accept vectors.
+Every case runs BOTH device engines (shift-and NFA and table DFA) where the automaton admits them."""
+import random
+
+import numpy as np
+import pytest
+
+import roaringregex_amd as rr
+from patterns import EMAIL, K1000, K1000_CONTAINS, KAT, U2, random_pattern, random_text
+from pyoracle import OracleError, OracleRegex
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+TILE, SEG, HALO = 32768, 128, 2048
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "GPU tests need a MI355X"
+
+
+def engines_for(pattern):
+    out = []
+    for e in (rr.ENGINE_NFA, rr.ENGINE_DFA):
+        try:
+            out.append(rr.RRegex(pattern, e))
+        except rr.RRegexError as err:
+            assert "too large" in str(err)
+    assert out, pattern
+    return out
+
+
+def check(pattern, data, oracle=None):
+    data = np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else data
+    o = oracle or OracleRegex(pattern)
+    want = o.match_lines(data)
+    corpus = rr.Corpus(torch.from_numpy(np.array(data, copy=True)).cuda() if len(data) else torch.empty(0, dtype=torch.uint8, device="cuda"))
+    assert corpus.num_lines == len(want)
+    for r in engines_for(pattern):
+        got = r.match_corpus(corpus).cpu().numpy()
+        assert got.shape == want.shape, (pattern[:40], r.engine_name)
+        bad = np.nonzero(got != want)[0]
+        assert bad.size == 0, (pattern[:40], r.engine_name, "first bad line", int(bad[0]), "of", len(want))
+    return want
+
+
+# ------------------------------------------------------------------------------------------ known answers
+def test_kat_batch():
+    for k in KAT["kat"]:
+        texts = [t for t in k["accepts"] + k["rejects"] if "\n" not in t]
+        data = ("\n".join(texts) + "\n").encode("latin-1")
+        want = check(k["pattern"], data)
+        exp = [1] * len([t for t in k["accepts"] if "\n" not in t]) + [0] * len([t for t in k["rejects"] if "\n" not in t])
+        assert list(want) == exp, k["pattern"]
+
+
+def test_kat_iterator_facade():
+    # regex.h:113-122,150-165: it = r.get_acceptance_iter(text); it++; *it
+    for k in KAT["kat"][:30] + KAT["kat"][-4:]:
+        for r in engines_for(k["pattern"]):
+            for t, want in [(t, True) for t in k["accepts"]] + [(t, False) for t in k["rejects"]]:
+                it = r.get_acceptance_iter(t)
+                it.advance()
+                m = it.value()
+                assert (m is not None) == want, (k["pattern"], t, r.engine_name)
+                if m is not None:
+                    assert m.start == 0 and m.end == len(t) and m.str() == t.encode("latin-1")
+                it.advance()                                        # idempotent after the terminator
+                assert (it.value() is not None) == want
+
+
+def test_iterator_before_advance_reflects_initial_set():
+    assert rr.RRegex("a*").get_acceptance_iter("b").value() is not None     # nullable: accepts before ++
+    assert rr.RRegex("a").get_acceptance_iter("a").value() is None
+    it = rr.RRegex("ab").get_acceptance_iter("ab")
+    c = it.create_copy()
+    it.advance()
+    assert it.value() is not None and c.value() is None                     # copies are independent
+
+
+def test_broken_reference_class_uses_intended_semantics():
+    for k in KAT["broken_reference"]:
+        for r in engines_for(k["pattern"]):
+            it = r.get_acceptance_iter(k["text"]).advance()
+            assert (it.value() is not None) == k["intended"]
+
+
+# ------------------------------------------------------------------------------------------ edge cases
+def test_empty_and_degenerate_inputs():
+    for p in ["a*", "a", ".*"]:
+        check(p, b"")
+        check(p, b"\n")
+        check(p, b"\n\n\n")
+        check(p, b"a")
+        check(p, b"a\n")
+        check(p, b"\na")
+        check(p, b"b\n\na\n\n")
+    check("a*", b"\n" * 5000)                       # only empty lines: one per byte
+    check("a*", b"a\n" * 40000)                     # 2-byte lines across several tiles
+
+
+def test_bytes_outside_the_domain_reject_their_line():
+    data = b"abc\nab\x00c\nabc\nab\x80c\n\xffabc\nabc"
+    want = check(".*", data)
+    assert list(want) == [1, 0, 1, 0, 0, 1]
+
+
+def _boundary_corpus(rng, total, cut_positions, alphabet=b"ab"):
+    a = np.frombuffer(bytes(rng.choice(alphabet) for _ in range(total)), dtype=np.uint8).copy()
+    for p in cut_positions:
+        if 0 <= p < total:
+            a[p] = 10
+    return a
+
+
+def test_lines_cut_exactly_at_segment_and_tile_boundaries():
+    rng = random.Random(5)
+    total = 3 * TILE + 777
+    for delta in (-2, -1, 0, 1):
+        cuts = [k * SEG + delta for k in range(1, total // SEG + 1, 3)] + [TILE + delta, 2 * TILE + delta, 3 * TILE + delta]
+        data = _boundary_corpus(rng, total, cuts)
+        check("(a|b)*abb(a|b)*", data)
+    # corpus sizes that are exact multiples of the tile, with and without a trailing newline
+    for n in (TILE, 2 * TILE):
+        data = _boundary_corpus(rng, n, range(50, n, 97))
+        check("(a|b)*abb(a|b)*", data)
+        data[-1] = 10
+        check("(a|b)*abb(a|b)*", data)
+
+
+def test_long_lines_through_halo_and_into_hbm():
+    rng = random.Random(6)
+    parts = []
+    for n in (SEG - 1, SEG, SEG + 1, 5 * SEG, HALO - 1, HALO, HALO + 1, HALO + SEG + 5, TILE - 1, TILE, TILE + 1, 2 * TILE + 300, 17):
+        body = bytes(rng.choice(b"ab") for _ in range(n))
+        parts.append(body)
+    data = b"\n".join(parts) + b"\n"
+    check("(a|b)*abb(a|b)*", np.frombuffer(data, dtype=np.uint8))
+    check("(a|b)*", np.frombuffer(data, dtype=np.uint8))
+    # one single unterminated string much longer than a tile (BASELINE config 1 shape)
+    one = np.frombuffer(bytes(rng.choice(b"abc") for _ in range(3 * TILE + 123)), dtype=np.uint8)
+    check("(a|b|c)*abc", one)
+
+
+def test_ragged_random_lines_small_alphabet():
+    rng = random.Random(7)
+    for p in ["ab*c", "(ab|cd)+", "a{2,5}b?", "[ab]+c[ab]*", "(a|b)*abb"]:
+        lines = [random_text(rng, "abcd", rng.choice([0, 1, 3, 8, 40, 200])) for _ in range(4000)]
+        check(p, ("\n".join(lines)).encode())
+
+
+# ------------------------------------------------------------------------------------------ random patterns
+def test_random_patterns_against_oracle():
+    rng = random.Random(99)
+    done = 0
+    while done < 60:
+        p = random_pattern(rng)
+        try:
+            o = OracleRegex(p)
+        except OracleError:
+            continue
+        if o.states_n > 300:
+            continue
+        try:
+            rr.RRegex(p)
+        except rr.RRegexError:
+            continue
+        lines = [random_text(rng, "abcxk01.d", rng.choice([2, 6, 12, 30])) for _ in range(1500)]
+        check(p, ("\n".join(lines) + "\n").encode(), oracle=o)
+        done += 1
+
+
+# ------------------------------------------------------------------------------------------ BASELINE configs
+def test_config_corpora_small():
+    import synth
+    cases = [("email", EMAIL, 4 << 20), ("url", U2, 4 << 20), ("arepeat", "a{1,300}", 96 << 10),
+             ("kwlines", K1000, 64 << 10), ("kwlog", K1000_CONTAINS, 128 << 10), ("c1", "abc", 1 << 20)]
+    for kind, pattern, nbytes in cases:
+        data = synth.corpus(kind, 11, nbytes)
+        want = check(pattern, data)
+        if kind in ("email", "url"):
+            assert 0.4 < want.mean() < 0.6
+
+
+def test_extents_api_treats_newline_as_an_ordinary_byte():
+    items = [b"a\nb", b"ab", b"", b"\n", b"a\n\nb", b"x"]
+    blob = b"".join(items)
+    off = np.cumsum([0] + [len(i) for i in items]).astype(np.int64)
+    data = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).cuda()
+    offs = torch.from_numpy(off).cuda()
+    o = OracleRegex("a.*b")
+    want = [int(o.accepts(i)) for i in items]
+    for r in engines_for("a.*b"):
+        got = r.match_extents(data, offs).cpu().numpy()
+        assert list(got) == want, r.engine_name
+
+
+def test_match_host_convenience():
+    data = b"abc\nabd\nabc"
+    assert list(rr.RRegex("abc").match_host(data)) == [1, 0, 1]
+    assert list(rr.RRegex("abc").match_host(b"")) == []
+
+
+# ------------------------------------------------------------------------------------------ full-size properties
+def test_full_size_email_config_properties():
+    """BASELINE config 2 at its full 1 GiB: the oracle cannot finish that in seconds, so check size-independent
+    properties: (1) both engines agree bit for bit; (2) the corpus is a concatenation of independently generated
+    1 MiB chunks, so the accept vector of chunk j taken alone must reappear at chunk j's line offset; a sample
+    of chunks is checked against the ORACLE; (3) the accept fraction stays near one half."""
+    import synth
+    n = 1 << 30
+    host = synth.corpus("email", 1, n)
+    dev = torch.from_numpy(host).cuda()
+    corpus = rr.Corpus(dev)
+    nfa = rr.RRegex(EMAIL, rr.ENGINE_NFA).match_corpus(corpus)
+    dfa = rr.RRegex(EMAIL, rr.ENGINE_DFA).match_corpus(corpus)
+    assert torch.equal(nfa, dfa)
+    acc = dfa.cpu().numpy()
+    assert 0.45 < acc.mean() < 0.55
+    chunk = 1 << 20
+    nl_before = np.cumsum(np.add.reduceat((host == 10).astype(np.int64), np.arange(0, n, chunk)))
+    o = OracleRegex(EMAIL)
+    for j in (0, 1, 17, 511, 1023):
+        piece = host[j * chunk:(j + 1) * chunk]
+        want = o.match_lines(piece)                 # every chunk ends with '\n' by construction
+        first = 0 if j == 0 else int(nl_before[j - 1])
+        assert (acc[first:first + len(want)] == want).all(), j

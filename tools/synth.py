@@ -1,0 +1,45 @@
+"""ctypes wrapper of tools/libsynth.so: deterministic synthetic corpora of the BASELINE configs."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KIND = {"c1": 1, "email": 2, "url": 3, "arepeat": 4, "kwlines": 5, "kwlog": 6}
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libsynth.so")
+        if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, "synth.c")):
+            subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+        L = C.CDLL(so)
+        L.synth_fill.restype = C.c_int
+        L.synth_fill.argtypes = [C.c_int, C.c_uint64, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
+        L.synth_fnv1a.restype = C.c_uint64
+        L.synth_fnv1a.argtypes = [C.c_void_p, C.c_size_t]
+        _LIB = L
+    return _LIB
+
+
+def fill(kind, seed, out, chunk=0, threads=None):
+    """Fill a writable uint8 numpy array (or anything exposing ctypes data) in place."""
+    if threads is None:
+        threads = min(os.cpu_count() or 1, 64)
+    rc = _lib().synth_fill(KIND[kind] if isinstance(kind, str) else kind, seed, C.c_void_p(out.ctypes.data), out.size, chunk, threads)
+    if rc:
+        raise RuntimeError("synth_fill failed: %d" % rc)
+    return out
+
+
+def corpus(kind, seed, nbytes, chunk=0, threads=None):
+    return fill(kind, seed, np.empty(nbytes, dtype=np.uint8), chunk, threads)
+
+
+def fnv1a(a):
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    return int(_lib().synth_fnv1a(C.c_void_p(a.ctypes.data), a.size))
