@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py — GB/s of input scanned by the RoaringRegex hot path on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+           bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (rrx_match_corpus: one kernel launch) over one resident batch: the
+256-state-class config of BASELINE.json (configs[2]): the URL regex U2 (226 reference states, BitSet<4> class)
+over 8 GiB of synthetic URL log lines per GPU.  The corpus and its newline index are resident in HBM before
+the timed region.  N > 1: every rank scans its own 8 GiB shard (weak scaling), no collective on the data path;
+torch.distributed (RCCL) is used only for the barrier and the max-over-ranks of the elapsed time.
+
+Prints ONE JSON line on rank 0 with the contract's fields plus "roofline" and "cpu_baseline".
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tools")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_ACHIEVABLE_GBS = 6290.0  # same guide: 6.29 TB/s measured float4 copy
+
+WORKLOADS = {
+    # name: (synth kind, pattern key, default bytes per GPU)
+    "url": ("url", "U2", 8 << 30),
+    "email": ("email", "EMAIL", 1 << 30),
+}
+
+
+def patterns():
+    with open(os.path.join(ROOT, "tests", "golden", "kat.json")) as f:
+        kat = json.load(f)
+    u2 = [k["pattern"] for k in kat["kat"] if k["pattern"].startswith("(http|https|ftp)")][0]
+    return {"U2": u2, "EMAIL": r"[A-Za-z0-9._]+@[A-Za-z0-9.]+"}
+
+
+def cpu_baseline(pattern, host, target_seconds=12.0):
+    """The oracle (CPU port of the reference's loop, NFA.cc:86-100) on a bounded sample of the same corpus,
+    one oracle instance per thread (the reference is not re-entrant either), all host cores."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from pyoracle import OracleRegex
+    cores = max(1, len(os.sched_getaffinity(0)))
+    chunk = 1 << 20                                    # corpus chunks end with '\n': line-aligned slices
+    # calibrate on 4 MiB, then size the sample for ~target_seconds
+    o = OracleRegex(pattern)
+    t0 = time.perf_counter()
+    o.match_lines(host[:4 * chunk])
+    per_core = 4 * chunk / (time.perf_counter() - t0)
+    per_thread = int(min(len(host) // cores, max(4 * chunk, per_core * target_seconds)) // chunk * chunk)
+    oracles = [OracleRegex(pattern) for _ in range(cores)]
+    accepted = [0] * cores
+
+    def work(i):
+        accepted[i] = int(oracles[i].match_lines(host[i * per_thread:(i + 1) * per_thread]).sum())
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    t0 = time.perf_counter()
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    dt = time.perf_counter() - t0
+    total = per_thread * cores
+    return {"value": round(total / dt / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": "port",
+            "sample": "first %d MiB of the same corpus, %d threads x %d MiB, oracle/rr_oracle.c (-O2)" % (total >> 20, cores, per_thread >> 20),
+            "single_core_GBs": round(per_core / 1e9, 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="url", choices=sorted(WORKLOADS))
+    ap.add_argument("--bytes", type=int, default=0, help="bytes per GPU (default: the BASELINE size)")
+    ap.add_argument("--engine", default="auto", choices=["auto", "nfa", "dfa"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+
+    import numpy as np
+    import torch
+    import roaringregex_amd as rr
+    import synth
+
+    assert torch.cuda.is_available(), "bench.py needs a MI355X"
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    kind, pkey, default_bytes = WORKLOADS[args.workload]
+    nbytes = args.bytes or default_bytes
+    pattern = patterns()[pkey]
+    engine = {"auto": rr.ENGINE_AUTO, "nfa": rr.ENGINE_NFA, "dfa": rr.ENGINE_DFA}[args.engine]
+    regex = rr.RRegex(pattern, engine, device=local_rank)
+
+    # ---- synthetic shard of this rank (seed differs per rank), generated on the host cores, then resident in HBM
+    t0 = time.perf_counter()
+    threads = max(1, len(os.sched_getaffinity(0)) // max(1, world))
+    host = np.empty(nbytes, dtype=np.uint8)
+    synth.fill(kind, 2 + 1000 * rank, host, threads=threads)
+    gen_s = time.perf_counter() - t0
+    dev = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    piece = 1 << 30
+    for off in range(0, nbytes, piece):
+        dev[off:off + piece].copy_(torch.from_numpy(host[off:off + piece]))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    corpus = rr.Corpus(dev)
+    torch.cuda.synchronize()
+    index_ms = (time.perf_counter() - t0) * 1e3
+    nlines = corpus.num_lines
+    out = torch.empty(nlines, dtype=torch.uint8, device="cuda")
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        regex.match_corpus(corpus, out=out)
+    barrier()
+    # HIP events on the stream the kernel is launched on (torch's current stream)
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record()
+        regex.match_corpus(corpus, out=out)
+        b.record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    accepted = int(out.sum(dtype=torch.int64).item())
+    if rank == 0:
+        avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
+        achieved = nbytes / avg_kernel_s / 1e9
+        res = {
+            "metric": "GB/s input scanned (whole job), 256-state regex" if args.workload == "url" else "GB/s input scanned (whole job)",
+            "value": round(world * nbytes * args.steps / elapsed / 1e9, 2),
+            "unit": "GB/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32" if regex.engine == rr.ENGINE_NFA else "u16",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: URL regex U2 (%d reference states, BitSet<%d> class) over %.2f GiB synthetic URL log lines per GPU"
+                                   % (regex.states_n, regex.set_class, nbytes / 2**30) if args.workload == "url" else
+                                   "BASELINE configs[1]: email regex (%d reference states) over %.2f GiB synthetic lines per GPU" % (regex.states_n, nbytes / 2**30),
+                       "pattern_states": regex.states_n, "useful_states": regex.useful_states, "engine": regex.engine_name,
+                       "bytes_per_gpu": nbytes, "lines_per_gpu": nlines, "accepted_rank0": accepted, "sharding": "by lines, no collective"},
+            "per_gpu_GBs": round(nbytes * args.steps / elapsed / 1e9, 2),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac_of_achievable_6.29TBs": round(achieved / HBM_ACHIEVABLE_GBS, 4),
+                         "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "algorithmic_bytes_per_launch": nbytes},
+            "setup": {"generate_s": round(gen_s, 2), "index_ms": round(index_ms, 3)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(pattern, host)
+        print(json.dumps(res), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
