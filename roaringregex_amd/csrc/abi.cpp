@@ -30,7 +30,8 @@ constexpr uint32_t kMaxSubsetStates = 16384;   // subset construction is abandon
 struct DeviceTables {
     void *blob = nullptr;
     dev::NfaDevice nfa;
-    dev::DfaDevice dfa;
+    dev::DfaDevice dfa;          // plain form (extents kernel)
+    dev::LineDfaDevice line;     // line-mode form (batch kernel)
 };
 
 int instantiated_width(uint32_t W) { return W <= 4 ? (int)W : W <= 6 ? 6 : 8; }
@@ -45,6 +46,7 @@ struct rrx_regex {
     NfaProgram nfa;
     DfaProgram dfa;
     int engine = 0;
+    bool line_wide = false;      // DFA engine: byte-indexed rows (<= kWideMaxStates states) or class-indexed rows
     mutable std::mutex mu;
     mutable std::map<int, DeviceTables> on_device;
 
@@ -61,7 +63,7 @@ struct rrx_regex {
         DeviceTables t;
         std::vector<uint8_t> host;
         auto put = [&](const void *p, size_t n) { size_t off = (host.size() + 15) & ~(size_t)15; host.resize(off + n); std::memcpy(host.data() + off, p, n); return off; };
-        size_t oB = 0, oX = 0, oC = 0, oN = 0, oA = 0;
+        size_t oB = 0, oX = 0, oC = 0, oN = 0, oA = 0, oT = 0, oL = 0;
         if (engine == RRX_ENGINE_NFA) {
             const uint32_t W = nfa.W, WP = (uint32_t)instantiated_width(W);
             std::vector<uint32_t> B((size_t)256 * WP, 0), X((size_t)nfa.nbits * WP, 0);
@@ -80,6 +82,32 @@ struct rrx_regex {
             oN = put(dfa.next.data(), dfa.next.size() * 2);
             oA = put(dfa.accepting.data(), dfa.accepting.size());
             t.dfa.nstates = dfa.nstates; t.dfa.ncls = dfa.ncls; t.dfa.start = dfa.start;
+            // line-mode table: entry = next row byte offset | nl << 30 | accept << 31; the '\n' column of every row
+            // goes to the start row and carries the verdict of the line that just ended.
+            const uint32_t D = dfa.nstates, K = dfa.ncls;
+            const bool wide = line_wide;
+            uint32_t stride = wide ? dev::kWideColumns : (K + 1);
+            if (!wide && !(stride & 1)) stride++;                       // odd row stride spreads rows over LDS banks
+            std::vector<uint32_t> T((size_t)D * stride, 0);
+            uint8_t lcls[256];
+            for (int c = 0; c < 256; c++) lcls[c] = dfa.cls[c];
+            lcls['\n'] = (uint8_t)K;                                     // own column for the line terminator
+            const uint32_t row_bytes = stride * 4;
+            for (uint32_t d = 0; d < D; d++) {
+                uint32_t *row = &T[(size_t)d * stride];
+                const uint32_t nl_entry = dfa.start * row_bytes | 1u << 30 | (dfa.accepting[d] ? 1u << 31 : 0u);
+                if (wide) {
+                    for (uint32_t c = 0; c < 128; c++) row[c] = (uint32_t)dfa.next[(size_t)d * K + dfa.cls[c]] * row_bytes;
+                    row['\n'] = nl_entry;
+                    row[128] = 0;
+                } else {
+                    for (uint32_t k = 0; k < K; k++) row[k] = (uint32_t)dfa.next[(size_t)d * K + k] * row_bytes;
+                    row[K] = nl_entry;
+                }
+            }
+            oT = put(T.data(), T.size() * 4);
+            oL = put(lcls, 256);
+            t.line.nrows = D; t.line.stride = stride; t.line.start_off = dfa.start * row_bytes; t.line.wide = wide ? 1 : 0;
         }
         HIP_TRY(hipMalloc(&t.blob, host.size() + 16));
         HIP_TRY(hipMemcpy(t.blob, host.data(), host.size(), hipMemcpyHostToDevice));
@@ -91,6 +119,8 @@ struct rrx_regex {
             t.dfa.cls = base + oC;
             t.dfa.next = reinterpret_cast<const uint16_t *>(base + oN);
             t.dfa.acc = base + oA;
+            t.line.table = reinterpret_cast<const uint32_t *>(base + oT);
+            t.line.cls = base + oL;
         }
         auto ins = on_device.emplace(device, t);
         *out = &ins.first->second;
@@ -101,7 +131,7 @@ struct rrx_regex {
 struct rrx_corpus {
     int device = 0;
     const uint8_t *d_bytes = nullptr;
-    size_t nbytes = 0, ntiles = 0, nlines = 0;
+    size_t nbytes = 0, nstripes = 0, nlines = 0;
     uint32_t *d_counts = nullptr;
     uint64_t *d_base = nullptr;
 };
@@ -122,7 +152,11 @@ int rrx_compile_ex(const char *pattern, int engine, rrx_regex **out) {
         if (engine != RRX_ENGINE_DFA) re->has_nfa = lower_nfa(re->trimmed, dev::kMaxNfaWords * 32, re->nfa);
         if (engine != RRX_ENGINE_NFA) {
             re->has_dfa = lower_dfa(re->trimmed, kMaxSubsetStates, re->dfa);
-            if (re->has_dfa && (size_t)re->dfa.nstates * re->dfa.ncls * 2 > dev::kDfaLdsBudget) re->has_dfa = false;
+            if (re->has_dfa) {
+                re->line_wide = re->dfa.nstates <= dev::kWideMaxStates;
+                const size_t classed = (size_t)re->dfa.nstates * (re->dfa.ncls + 2) * 4 + 256;
+                if (!re->line_wide && classed > dev::kClassedLdsBudget) re->has_dfa = false;
+            }
         }
     } catch (const PatternError &e) {
         delete re;
@@ -156,7 +190,9 @@ uint32_t rrx_ref_row(const rrx_regex *re, uint32_t state, unsigned c, uint32_t *
     return (uint32_t)r.size();
 }
 int rrx_engine(const rrx_regex *re) { return re->engine; }
-const char *rrx_engine_name(const rrx_regex *re) { return re->engine == RRX_ENGINE_DFA ? "dfa-table" : "nfa-shift-and"; }
+const char *rrx_engine_name(const rrx_regex *re) {
+    return re->engine == RRX_ENGINE_DFA ? (re->line_wide ? "dfa-wide-table" : "dfa-classed-table") : "nfa-shift-and";
+}
 uint32_t rrx_useful_states(const rrx_regex *re) { return re->trimmed.n; }
 uint32_t rrx_byte_classes(const rrx_regex *re) { return re->trimmed.ncls; }
 uint32_t rrx_words_per_set(const rrx_regex *re) { return re->has_nfa ? re->nfa.W : 0; }
@@ -187,16 +223,16 @@ int rrx_corpus_create(int device, const void *d_bytes, size_t nbytes, void *stre
     c->device = device;
     c->d_bytes = static_cast<const uint8_t *>(d_bytes);
     c->nbytes = nbytes;
-    c->ntiles = (nbytes + dev::kTile - 1) / dev::kTile;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->d_counts), (c->ntiles + 1) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_base), (c->ntiles + 1) * sizeof(uint64_t));
+    c->nstripes = (nbytes + dev::kStripe - 1) / dev::kStripe;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->d_counts), (c->nstripes + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_base), (c->nstripes + 1) * sizeof(uint64_t));
     if (e != hipSuccess) { rrx_corpus_free(c); return hip_fail(e, "hipMalloc(line index)"); }
-    int rc = dev::count_newlines_per_tile(c->d_bytes, nbytes, c->d_counts, c->ntiles, stream);
-    if (!rc) rc = dev::scan_tile_counts(c->d_counts, c->d_base, c->ntiles, stream);
+    int rc = dev::count_newlines_per_stripe(c->d_bytes, nbytes, c->d_counts, c->nstripes, stream);
+    if (!rc) rc = dev::scan_counts(c->d_counts, c->d_base, c->nstripes, stream);
     if (rc) { rrx_corpus_free(c); return hip_fail((hipError_t)rc, "line index launch"); }
     uint64_t total = 0;
     uint8_t last = '\n';
-    e = hipMemcpyAsync(&total, c->d_base + c->ntiles, sizeof total, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    e = hipMemcpyAsync(&total, c->d_base + c->nstripes, sizeof total, hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess && nbytes) e = hipMemcpyAsync(&last, c->d_bytes + nbytes - 1, 1, hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) { rrx_corpus_free(c); return hip_fail(e, "line index readback"); }
@@ -221,9 +257,9 @@ int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint8_t *d_accept
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
     int e = re->engine == RRX_ENGINE_NFA
-                ? dev::match_tiles_nfa(t->nfa, c->d_bytes, c->nbytes, c->d_base, c->ntiles, d_accept, stream)
-                : dev::match_tiles_dfa(t->dfa, c->d_bytes, c->nbytes, c->d_base, c->ntiles, d_accept, stream);
-    if (e) return hip_fail((hipError_t)e, "match_tiles launch");
+                ? dev::match_stripes_nfa(t->nfa, c->d_bytes, c->nbytes, c->d_base, c->nstripes, d_accept, stream)
+                : dev::match_stripes_dfa(t->line, c->d_bytes, c->nbytes, c->d_base, c->nstripes, d_accept, stream);
+    if (e) return hip_fail((hipError_t)e, "match_stripes launch");
     return RRX_OK;
 }
 

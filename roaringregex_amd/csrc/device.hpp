@@ -6,41 +6,55 @@
 namespace rrx {
 namespace dev {
 
-// Geometry of the batch kernel: a workgroup scans one TILE of the corpus; lane l owns the lines that
-// START in bytes [l*SEG, (l+1)*SEG) of the tile and follows its last line past the segment end.
+// Geometry of the batch kernel: lane g of the grid owns the lines that START in the contiguous stripe
+// bytes [g*kStripe, (g+1)*kStripe) and follows its last line past the stripe end.  Every lane streams its
+// stripe straight from HBM into registers, kRound bytes (4 x 16 B) per round.
 constexpr int kThreads = 256;
-constexpr int kSeg = 128;
-constexpr int kTile = kThreads * kSeg;          // 32 KiB of text per workgroup
-constexpr int kHalo = 2048;                     // look-ahead staged in LDS; longer lines read HBM directly
-constexpr int kMaxNfaWords = 8;                 // 256 positions per lane-resident state set
-constexpr uint32_t kDfaLdsBudget = 96 * 1024;   // table bytes that may live in LDS next to the text tile
+constexpr int kStripe = 4096;
+constexpr int kRound = 64;
+constexpr int kMaxNfaWords = 8;                  // 256 positions per lane-resident state set
+constexpr uint32_t kWideColumns = 129;           // columns 0..127 = byte values, 128 = any byte >= 0x80
+constexpr uint32_t kWideMaxStates = 127;         // row byte offsets must fit 16 bits
+constexpr uint32_t kClassedLdsBudget = 120 * 1024;
 
-struct NfaMasks {                               // passed by value -> SGPRs
+struct NfaMasks {                                // passed by value -> SGPRs
     uint32_t init[kMaxNfaWords], fin[kMaxNfaWords], chain[kMaxNfaWords], self[kMaxNfaWords], excm[kMaxNfaWords];
 };
 
-struct NfaDevice {                              // tables in HBM (copied to LDS by every workgroup)
+struct NfaDevice {                               // tables in HBM (copied to LDS by every workgroup)
     uint32_t W = 0, nbits = 0, any_exc = 0;
     NfaMasks masks;
-    const uint32_t *B = nullptr;                // [256][W]
-    const uint32_t *X = nullptr;                // [nbits][W]
+    const uint32_t *B = nullptr;                 // [256][W]
+    const uint32_t *X = nullptr;                 // [nbits][W]
 };
 
+// Plain DFA (extents kernel: '\n' is an ordinary byte).
 struct DfaDevice {
     uint32_t nstates = 0, ncls = 0, start = 0;
-    const uint8_t *cls = nullptr;               // [256]
-    const uint16_t *next = nullptr;             // [nstates][ncls]
-    const uint8_t *acc = nullptr;               // [nstates]
+    const uint8_t *cls = nullptr;                // [256]
+    const uint16_t *next = nullptr;              // [nstates][ncls]
+    const uint8_t *acc = nullptr;                // [nstates]
+};
+
+// Line-mode DFA tables (batch kernel): the '\n' transition of every row goes to the start row and carries
+// the verdict of the line that just ended.  Entry = next row byte offset | nl << 30 | accept << 31.
+struct LineDfaDevice {
+    uint32_t nrows = 0;                          // rows (row 0 = dead)
+    uint32_t stride = 0;                         // entries per row
+    uint32_t start_off = 0;                      // byte offset of the start row
+    uint32_t wide = 0;                           // 1: columns are byte values (kWideColumns); 0: byte classes
+    const uint32_t *table = nullptr;             // [nrows][stride]
+    const uint8_t *cls = nullptr;                // [256] (classed form only)
 };
 
 // All launchers are asynchronous on `stream` and return a hipError_t value (0 = success).
-int count_newlines_per_tile(const uint8_t *bytes, size_t nbytes, uint32_t *tile_counts, size_t ntiles, void *stream);
-int scan_tile_counts(const uint32_t *tile_counts, uint64_t *tile_base, size_t ntiles, void *stream);
+int count_newlines_per_stripe(const uint8_t *bytes, size_t nbytes, uint32_t *counts, size_t nstripes, void *stream);
+int scan_counts(const uint32_t *counts, uint64_t *base, size_t n, void *stream);
 
-int match_tiles_nfa(const NfaDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *tile_base,
-                    size_t ntiles, uint8_t *accept, void *stream);
-int match_tiles_dfa(const DfaDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *tile_base,
-                    size_t ntiles, uint8_t *accept, void *stream);
+int match_stripes_nfa(const NfaDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *stripe_base,
+                      size_t nstripes, uint8_t *accept, void *stream);
+int match_stripes_dfa(const LineDfaDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *stripe_base,
+                      size_t nstripes, uint8_t *accept, void *stream);
 
 // items i = bytes[off[i] .. off[i+1] - trim) ; trim = 1 drops a trailing delimiter byte per item
 int match_extents_nfa(const NfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim,

@@ -6,16 +6,16 @@
 //   Processor::operator*()                NFA.cc:103-107    (accepting?)
 // Pure integer/bitwise work, HBM-read bound by design: no MFMA.
 //
-// Batch kernel (match_tiles<Engine>):
-//   * one 256-thread workgroup per 32 KiB tile of text; the tile (+ a look-ahead halo) is staged into LDS
-//     with coalesced 16 B/lane loads and an XOR swizzle of the 16-byte unit index, so that the per-lane
-//     strided ds_read_b128 of "my 128-byte segment" is bank-conflict free;
-//   * lane l scans the lines that START in its segment and follows the last one past the segment end
-//     (into LDS halo, then HBM), so every line is stepped by exactly one lane from its first byte;
-//   * the automaton tables live in LDS, the state set lives in registers;
-//   * per 16-byte unit a lane ORs {newline mask, accept mask} into a positional LDS bitmap; after a
-//     barrier the workgroup ranks the newline bits (popcount + block scan) and writes accept[line]
-//     with line = tile_base[tile] + rank: no line-offset array is ever read.
+// Batch kernel (match_stripes<Engine>) — the text never touches LDS:
+//   * lane g of the grid owns the lines that START in its contiguous 4 KiB stripe of the corpus and follows
+//     its last line past the stripe end, so every line is stepped by exactly one lane from its first byte;
+//   * each lane streams its own stripe from HBM straight into registers, 64 bytes (4 x global_load_dwordx4)
+//     per round, the next round's loads in flight while the current one is stepped (measured: this per-lane
+//     streaming pattern reads at the same 6.3-6.4 TB/s as a fully coalesced copy, profiles/r01_membench*);
+//   * the automaton tables live in LDS, the state lives in registers;
+//   * line results are accumulated in a register as ordered bits and flushed once per round as byte stores
+//     accept[line]; line = stripe_base[g] + newlines seen so far, stripe_base being the per-stripe newline
+//     prefix the corpus carries (8 bytes per 4 KiB of text): no per-line offset array is ever read.
 #include <hip/hip_runtime.h>
 
 #include "device.hpp"
@@ -24,15 +24,50 @@ namespace rrx {
 namespace dev {
 namespace {
 
-constexpr int kUnits = (kTile + kHalo) / 16;        // staged 16-byte units
-constexpr int kBitWords = kTile / 16;               // one u32 {nl:16, acc:16} per tile unit
+// ============================================================================================ engines
+// Line-mode engines expose
+//     void load(program, lds)               cooperative table copy into LDS
+//     State fresh() / State skipping()      start of a line / inside a line owned by somebody else
+//     void step(State&, c, nl, acc)         consume one byte; nl = 1 iff it was '\n', acc = verdict of the
+//                                           line it ended (valid when nl)
 
-__device__ __forceinline__ int swz(int unit) { return unit ^ ((unit >> 4) & 15); }
+// ---- wide / classed table DFA: '\n' handling folded into the table -------------------------------
+template <bool WIDE>
+struct LineDfaEngine {
+    struct State { uint32_t e; };          // last table entry; low 30 bits = current row byte offset
+    const uint8_t *tab;                    // LDS, byte-addressed
+    const uint8_t *cls;                    // LDS [256] (classed form)
+    uint32_t start_off;
 
-// ------------------------------------------------------------------------------------------ engines
+    static size_t lds_bytes(const LineDfaDevice &p) { return (size_t)p.nrows * p.stride * 4 + (WIDE ? 0 : 256); }
+    __device__ void load(const LineDfaDevice &p, uint8_t *lds) {
+        uint32_t *t = reinterpret_cast<uint32_t *>(lds);
+        const int n = (int)(p.nrows * p.stride);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) t[i] = p.table[i];
+        if (!WIDE) {
+            uint8_t *c = lds + (size_t)n * 4;
+            for (int i = threadIdx.x; i < 256; i += blockDim.x) c[i] = p.cls[i];
+            cls = c;
+        }
+        tab = lds;
+        start_off = p.start_off;
+    }
+    __device__ __forceinline__ State fresh() const { return State{start_off}; }
+    __device__ __forceinline__ State skipping() const { return State{0}; }          // dead row: waits for '\n'
+    __device__ __forceinline__ void step(State &st, uint32_t c, uint32_t &nl, uint32_t &acc) const {
+        uint32_t col;
+        if (WIDE) col = c < 128u ? c : 128u;
+        else col = cls[c];
+        const uint32_t off = (st.e & 0x3fffffffu) + col * 4u;
+        st.e = *reinterpret_cast<const uint32_t *>(tab + off);
+        nl = (st.e >> 30) & 1u;
+        acc = st.e >> 31;
+    }
+};
+
+// ---- shift-and NFA: state set in W registers --------------------------------------------------------
 template <int W>
-struct NfaEngine {
-    static constexpr int kWords = W;
+struct NfaCore {
     struct State { uint32_t s[W]; };
     const uint32_t *B;      // LDS [256][W]
     const uint32_t *X;      // LDS [nbits][W]
@@ -40,21 +75,12 @@ struct NfaEngine {
     bool any_exc;
 
     static size_t lds_bytes(const NfaDevice &p) { return ((size_t)256 * W + (size_t)p.nbits * W) * 4; }
-
     __device__ void load(const NfaDevice &p, uint8_t *lds) {
         uint32_t *b = reinterpret_cast<uint32_t *>(lds);
         uint32_t *x = b + 256 * W;
         for (int i = threadIdx.x; i < 256 * W; i += blockDim.x) b[i] = p.B[i];
         for (int i = threadIdx.x; i < (int)p.nbits * W; i += blockDim.x) x[i] = p.X[i];
         B = b; X = x; m = p.masks; any_exc = p.any_exc != 0;
-    }
-    __device__ __forceinline__ void reset(State &st) const {
-#pragma unroll
-        for (int i = 0; i < W; i++) st.s[i] = m.init[i];
-    }
-    __device__ __forceinline__ void kill(State &st) const {
-#pragma unroll
-        for (int i = 0; i < W; i++) st.s[i] = 0;
     }
     __device__ __forceinline__ bool accepting(const State &st) const {
         uint32_t a = 0;
@@ -63,7 +89,7 @@ struct NfaEngine {
         return a != 0;
     }
     // next = ( ((S << 1) & CHAIN) | (S & SELF) | OR_{e in S & EXC} X[e] ) & B[c]
-    __device__ __forceinline__ void step(State &st, uint32_t c) const {
+    __device__ __forceinline__ void advance(State &st, uint32_t c) const {
         uint32_t t[W];
         uint32_t exc = 0;
 #pragma unroll
@@ -92,7 +118,50 @@ struct NfaEngine {
     }
 };
 
-struct DfaEngine {
+template <int W>
+struct LineNfaEngine : NfaCore<W> {
+    using State = typename NfaCore<W>::State;
+    __device__ __forceinline__ State fresh() const {
+        State st;
+#pragma unroll
+        for (int i = 0; i < W; i++) st.s[i] = this->m.init[i];
+        return st;
+    }
+    __device__ __forceinline__ State skipping() const {
+        State st;
+#pragma unroll
+        for (int i = 0; i < W; i++) st.s[i] = 0;
+        return st;
+    }
+    __device__ __forceinline__ void step(State &st, uint32_t c, uint32_t &nl, uint32_t &acc) const {
+        const bool isnl = c == '\n';
+        const bool a = this->accepting(st);
+        this->advance(st, c);                      // B['\n'] and B[0], B[>=0x80] are empty rows: the set dies
+        if (isnl) {
+#pragma unroll
+            for (int i = 0; i < W; i++) st.s[i] = this->m.init[i];
+        }
+        nl = isnl ? 1u : 0u;
+        acc = (isnl && a) ? 1u : 0u;
+    }
+};
+
+// ---- plain engines for the extents kernel ('\n' is an ordinary byte) --------------------------------
+template <int W>
+struct PlainNfaEngine : NfaCore<W> {
+    using State = typename NfaCore<W>::State;
+    __device__ __forceinline__ void reset(State &st) const {
+#pragma unroll
+        for (int i = 0; i < W; i++) st.s[i] = this->m.init[i];
+    }
+    __device__ __forceinline__ void kill(State &st) const {
+#pragma unroll
+        for (int i = 0; i < W; i++) st.s[i] = 0;
+    }
+    __device__ __forceinline__ void step(State &st, uint32_t c) const { this->advance(st, c); }
+};
+
+struct PlainDfaEngine {
     struct State { uint32_t s; };
     const uint8_t *cls;     // LDS [256]
     const uint16_t *next;   // LDS [nstates][ncls]
@@ -100,8 +169,7 @@ struct DfaEngine {
     uint32_t ncls, start;
 
     static size_t lds_bytes(const DfaDevice &p) {
-        size_t t = (size_t)p.nstates * p.ncls * 2;
-        t = (t + 15) & ~(size_t)15;
+        size_t t = ((size_t)p.nstates * p.ncls * 2 + 15) & ~(size_t)15;
         return t + 256 + ((p.nstates + 15) & ~15u);
     }
     __device__ void load(const DfaDevice &p, uint8_t *lds) {
@@ -120,129 +188,116 @@ struct DfaEngine {
     __device__ __forceinline__ void step(State &st, uint32_t c) const { st.s = next[st.s * ncls + cls[c]]; }
 };
 
-// ------------------------------------------------------------------------------------------ batch kernel
-template <class Engine, class Program>
-__global__ __launch_bounds__(kThreads) void match_tiles_kernel(Program prog, const uint8_t *__restrict__ bytes, size_t nbytes,
-                                                                const uint64_t *__restrict__ tile_base, size_t ntiles,
-                                                                uint8_t *__restrict__ accept) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint4 *text = reinterpret_cast<uint4 *>(smem);                             // kUnits swizzled 16-byte units
-    uint32_t *bits = reinterpret_cast<uint32_t *>(smem + (size_t)kUnits * 16); // kBitWords
-    uint32_t *scan = bits + kBitWords;                                         // 8 words
-    uint8_t *tables = reinterpret_cast<uint8_t *>(scan + 8);
+// ============================================================================================ batch kernel
+// Ordered line results of one lane: `bits` holds a sentinel 1 followed by one verdict bit per finished line
+// (oldest highest).  flush() stores them as bytes accept[line++]; the first result of a lane that started
+// inside somebody else's line belongs to that somebody and is dropped (it is still counted).
+struct Results {
+    uint32_t bits = 1;
+    uint64_t line;
+    bool drop_first;
+    uint8_t *__restrict__ accept;
 
-    const size_t tile = blockIdx.x;
-    const size_t tile_start = tile * (size_t)kTile;
-    const int tid = threadIdx.x;
-
-    Engine eng;
-    eng.load(prog, tables);
-
-    // ---- stage text: coalesced 16 B per lane, swizzled unit index
-    const size_t avail = nbytes - tile_start;                                  // > 0 by construction of the grid
-    for (int u = tid; u < kUnits; u += kThreads) {
-        size_t off = (size_t)u * 16;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (off + 16 <= avail) v = *reinterpret_cast<const uint4 *>(bytes + tile_start + off);
-        else if (off < avail) {
-            uint32_t w[4] = {0, 0, 0, 0};
-            for (size_t k = 0; off + k < avail; k++) w[k >> 2] |= (uint32_t)bytes[tile_start + off + k] << (8 * (k & 3));
-            v = make_uint4(w[0], w[1], w[2], w[3]);
+    __device__ __forceinline__ void push(uint32_t nl, uint32_t acc) { bits = (bits << nl) | acc; }
+    __device__ __forceinline__ void flush() {
+        int n = 31 - __clz((int)bits);
+        while (__any(n > 0)) {
+            if (n > 0) {
+                n--;
+                if (drop_first) drop_first = false;
+                else accept[line] = (uint8_t)((bits >> n) & 1u);
+                line++;
+            }
         }
-        text[swz(u)] = v;
+        bits = 1;
     }
-    for (int i = tid; i < kBitWords; i += kThreads) bits[i] = 0;
-    const bool tile_mid_line = tile_start > 0 && bytes[tile_start - 1] != '\n';
+    // same, for code that runs with lanes diverged (no wave-wide vote)
+    __device__ __forceinline__ void flush_lane() {
+        for (int n = 31 - __clz((int)bits); n > 0;) {
+            n--;
+            if (drop_first) drop_first = false;
+            else accept[line] = (uint8_t)((bits >> n) & 1u);
+            line++;
+        }
+        bits = 1;
+    }
+};
+
+template <class Engine, class Program>
+__global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, const uint8_t *__restrict__ bytes, size_t nbytes,
+                                                                  const uint64_t *__restrict__ stripe_base,
+                                                                  uint8_t *__restrict__ accept) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    Engine eng;
+    eng.load(prog, smem);
     __syncthreads();
 
-    // ---- scan my segment
-    const size_t seg_start = tile_start + (size_t)tid * kSeg;
-    if (seg_start < nbytes) {
-        const size_t seg_end = seg_start + kSeg;
-        bool active;
-        if (tid == 0) active = !tile_mid_line;
-        else {
-            int prev = tid * kSeg - 1;
-            const uint8_t *tb = reinterpret_cast<const uint8_t *>(&text[swz(prev >> 4)]);
-            active = tb[prev & 15] == '\n';
+    const size_t g = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    const size_t start = g * (size_t)kStripe;
+    if (start >= nbytes) return;
+    const size_t stripe_end = start + kStripe;
+    const size_t my_end = stripe_end < nbytes ? stripe_end : nbytes;
+    const bool fresh = start == 0 || bytes[start - 1] == '\n';
+    typename Engine::State st = fresh ? eng.fresh() : eng.skipping();
+    Results res;
+    res.line = stripe_base[g];
+    res.drop_first = !fresh;
+    res.accept = accept;
+    const uint64_t first_line = res.line;
+
+    // ---- main phase: whole 64-byte rounds of my stripe, next round's loads in flight
+    size_t pos = start;
+    const uint4 *src = reinterpret_cast<const uint4 *>(bytes + start);
+    const int rounds = (int)((my_end - start) / kRound);
+    uint4 cur[4], nxt[4];
+    if (rounds > 0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) cur[i] = src[i];
+    }
+    for (int r = 0; r < rounds; r++) {
+        if (r + 1 < rounds) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) nxt[i] = src[(r + 1) * 4 + i];
         }
-        typename Engine::State st;
-        eng.reset(st);
-        bool boundary = true;          // the next byte starts a line
-        bool done = false;
-        for (int u = tid * (kSeg / 16); !done; u++) {
-            const size_t pos = tile_start + (size_t)u * 16;
-            uint32_t w[4] = {0, 0, 0, 0};
-            if (u < kUnits) {
-                uint4 v = text[swz(u)];
-                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-            } else if (pos + 16 <= nbytes) {
-                uint4 v = *reinterpret_cast<const uint4 *>(bytes + pos);
-                w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-            } else {
-                for (size_t k = 0; pos + k < nbytes; k++) w[k >> 2] |= (uint32_t)bytes[pos + k] << (8 * (k & 3));
-            }
-            uint32_t unit_bits = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t w[4] = {cur[i].x, cur[i].y, cur[i].z, cur[i].w};
 #pragma unroll
             for (int k = 0; k < 16; k++) {
-                if (done) break;
-                const size_t p = pos + k;
-                bool is_end = p >= nbytes;
-                uint32_t c = (w[k >> 2] >> (8 * (k & 3))) & 0xff;
-                if (is_end) {
-                    // end of corpus terminates an unfinished last line like a '\n' would
-                    if (!(active && !boundary)) { done = true; break; }
-                    c = '\n';
-                }
-                if (c == '\n') {
-                    if (active) {
-                        uint32_t a = eng.accepting(st) ? 0x10001u : 0x1u;
-                        if (p < tile_start + kTile) unit_bits |= a << k;
-                        else accept[tile_base[p / kTile]] = (uint8_t)(a >> 16);
-                    }
-                    active = true;
-                    boundary = true;
-                    eng.reset(st);
-                    if (is_end || p + 1 >= seg_end) done = true;
-                } else {
-                    if (!active && p + 1 >= seg_end) { done = true; break; }
-                    if (active) {
-                        if (c == 0 || c >= 0x80) eng.kill(st); else eng.step(st, c);
-                    }
-                    boundary = false;
-                }
+                uint32_t nl, acc;
+                eng.step(st, (w[k >> 2] >> (8 * (k & 3))) & 0xffu, nl, acc);
+                res.push(nl, acc);
             }
-            if (unit_bits) atomicOr(&bits[u], unit_bits);       // u < kBitWords whenever unit_bits != 0
+            if (__any(res.bits >> 15)) res.flush();      // <= 16 more results fit before the next check
         }
+        res.flush();
+#pragma unroll
+        for (int i = 0; i < 4; i++) cur[i] = nxt[i];
     }
-    __syncthreads();
+    pos += (size_t)rounds * kRound;
 
-    // ---- rank the newline bits of the tile and write accept[line]
-    uint32_t mine[kSeg / 16];
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int i = 0; i < kSeg / 16; i++) { mine[i] = bits[tid * (kSeg / 16) + i]; cnt += __popc(mine[i] & 0xffffu); }
-    uint32_t incl = cnt;
-    const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
-    if (lane == 63) scan[wave] = incl;
-    __syncthreads();
-    uint32_t wave_off = 0;
-    for (int i = 0; i < wave; i++) wave_off += scan[i];
-    uint64_t line = tile_base[tile] + (tile_mid_line ? 1 : 0) + wave_off + (incl - cnt);
-#pragma unroll
-    for (int i = 0; i < kSeg / 16; i++) {
-        uint32_t nl = mine[i] & 0xffffu, ac = mine[i] >> 16;
-        while (nl) {
-            int b = __ffs(nl) - 1;
-            nl &= nl - 1;
-            accept[line++] = (uint8_t)((ac >> b) & 1);
-        }
+    // ---- tail of the corpus inside my stripe (only the last stripe has one), byte by byte
+    for (; pos < my_end; pos++) {
+        uint32_t nl, acc;
+        eng.step(st, bytes[pos], nl, acc);
+        res.push(nl, acc);
+        if (res.bits >> 30) res.flush_lane();
+    }
+    res.flush_lane();
+
+    // ---- follow my last line past the stripe end.  It is mine iff I started it: I began at a line start or
+    // saw a '\n' inside my stripe, and my stripe does not end exactly on a '\n'.
+    const bool started = fresh || res.line > first_line;
+    if (started && bytes[my_end - 1] != '\n') {
+        uint32_t nl = 0, acc = 0;
+        for (; pos < nbytes && !nl; pos++) eng.step(st, bytes[pos], nl, acc);
+        if (!nl) eng.step(st, '\n', nl, acc);       // the corpus ends without '\n': end of data ends the line
+        res.push(nl, acc);
+        res.flush_lane();
     }
 }
 
-// ------------------------------------------------------------------------------------------ extents kernel
+// ============================================================================================ extents kernel
 // One lane per item; bytes come straight from HBM/L2.  Used for explicit (offset,len) batches, for the
 // iterator facade's single strings, and wherever '\n' is an ordinary character.
 template <class Engine, class Program>
@@ -267,40 +322,42 @@ __global__ __launch_bounds__(kThreads) void match_extents_kernel(Program prog, c
     accept[i] = eng.accepting(st) ? 1 : 0;
 }
 
-// ------------------------------------------------------------------------------------------ line index
+// ============================================================================================ line index
+// counts[g] = number of '\n' in stripe g, streamed exactly like the match kernel streams it.
 __global__ __launch_bounds__(kThreads) void count_newlines_kernel(const uint8_t *__restrict__ bytes, size_t nbytes,
-                                                                   uint32_t *__restrict__ counts) {
-    __shared__ uint32_t part[kThreads / 64];
-    const size_t tile_start = (size_t)blockIdx.x * kTile;
-    const size_t avail = nbytes - tile_start < (size_t)kTile ? nbytes - tile_start : (size_t)kTile;
+                                                                   uint32_t *__restrict__ counts, size_t nstripes) {
+    const size_t g = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    if (g >= nstripes) return;
+    const size_t start = g * (size_t)kStripe;
+    const size_t end = start + kStripe < nbytes ? start + kStripe : nbytes;
+    const uint4 *src = reinterpret_cast<const uint4 *>(bytes + start);
+    const int units = (int)((end - start) / 16);
     uint32_t cnt = 0;
-    for (int u = threadIdx.x; u < kTile / 16; u += kThreads) {
-        size_t o = (size_t)u * 16;
-        if (o + 16 <= avail) {
-            uint4 v = *reinterpret_cast<const uint4 *>(bytes + tile_start + o);
-            uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    int u = 0;
+    for (; u + 4 <= units; u += 4) {
+        uint4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = src[u + i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                uint32_t x = w[j] ^ 0x0a0a0a0au;                          // zero byte <=> '\n'
-                uint32_t z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);   // exact zero-byte test
+                uint32_t x = w[j] ^ 0x0a0a0a0au;                                        // zero byte <=> '\n'
+                uint32_t z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);    // exact zero-byte test
                 cnt += __popc(z);
             }
-        } else {
-            for (size_t k = o; k < avail && k < o + 16; k++) cnt += bytes[tile_start + k] == '\n';
         }
     }
-#pragma unroll
-    for (int d = 32; d; d >>= 1) cnt += __shfl_down(cnt, d, 64);
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) counts[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+    for (size_t p = start + (size_t)u * 16; p < end; p++) cnt += bytes[p] == '\n';
+    counts[g] = cnt;
 }
 
-// exclusive scan of ntiles counts into ntiles+1 bases (single workgroup, chunked)
+// exclusive scan of n counts into n+1 bases (single workgroup, chunked)
 __global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t *__restrict__ counts, uint64_t *__restrict__ base, size_t n) {
     __shared__ uint64_t sums[1024];
     const size_t chunk = (n + 1023) / 1024;
-    const size_t lo = threadIdx.x * chunk, hi = lo + chunk < n ? lo + chunk : n;
+    const size_t lo = threadIdx.x * chunk < n ? threadIdx.x * chunk : n, hi = lo + chunk < n ? lo + chunk : n;
     uint64_t s = 0;
     for (size_t i = lo; i < hi; i++) s += counts[i];
     sums[threadIdx.x] = s;
@@ -316,14 +373,14 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t *__res
 }
 
 template <class Engine, class Program>
-int launch_tiles(const Program &p, size_t table_bytes, const uint8_t *bytes, size_t nbytes, const uint64_t *tile_base, size_t ntiles,
-                 uint8_t *accept, void *stream) {
-    if (!ntiles) return 0;
-    size_t lds = (size_t)kUnits * 16 + (size_t)kBitWords * 4 + 32 + table_bytes;
-    auto k = match_tiles_kernel<Engine, Program>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+int launch_stripes(const Program &p, size_t table_bytes, const uint8_t *bytes, size_t nbytes, const uint64_t *stripe_base,
+                   size_t nstripes, uint8_t *accept, void *stream) {
+    if (!nstripes) return 0;
+    auto k = match_stripes_kernel<Engine, Program>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)table_bytes);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(k, dim3((unsigned)ntiles), dim3(kThreads), lds, (hipStream_t)stream, p, bytes, nbytes, tile_base, ntiles, accept);
+    size_t blocks = (nstripes + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), table_bytes, (hipStream_t)stream, p, bytes, nbytes, stripe_base, accept);
     return (int)hipGetLastError();
 }
 
@@ -341,13 +398,14 @@ int launch_extents(const Program &p, size_t table_bytes, const uint8_t *bytes, c
 
 }  // namespace
 
-int count_newlines_per_tile(const uint8_t *bytes, size_t nbytes, uint32_t *tile_counts, size_t ntiles, void *stream) {
-    if (!ntiles) return 0;
-    hipLaunchKernelGGL(count_newlines_kernel, dim3((unsigned)ntiles), dim3(kThreads), 0, (hipStream_t)stream, bytes, nbytes, tile_counts);
+int count_newlines_per_stripe(const uint8_t *bytes, size_t nbytes, uint32_t *counts, size_t nstripes, void *stream) {
+    if (!nstripes) return 0;
+    size_t blocks = (nstripes + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(count_newlines_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, bytes, nbytes, counts, nstripes);
     return (int)hipGetLastError();
 }
-int scan_tile_counts(const uint32_t *tile_counts, uint64_t *tile_base, size_t ntiles, void *stream) {
-    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, tile_counts, tile_base, ntiles);
+int scan_counts(const uint32_t *counts, uint64_t *base, size_t n, void *stream) {
+    hipLaunchKernelGGL(scan_counts_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, counts, base, n);
     return (int)hipGetLastError();
 }
 
@@ -363,25 +421,26 @@ int scan_tile_counts(const uint32_t *tile_counts, uint64_t *tile_base, size_t nt
     }
 
 // The device tables are padded to the instantiated width by the caller (NfaDevice::W is the padded width).
-int match_tiles_nfa(const NfaDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *tile_base, size_t ntiles,
-                    uint8_t *accept, void *stream) {
-#define CALL(WW) launch_tiles<NfaEngine<WW>, NfaDevice>(p, NfaEngine<WW>::lds_bytes(p), bytes, nbytes, tile_base, ntiles, accept, stream)
+int match_stripes_nfa(const NfaDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *stripe_base, size_t nstripes,
+                      uint8_t *accept, void *stream) {
+#define CALL(WW) launch_stripes<LineNfaEngine<WW>, NfaDevice>(p, LineNfaEngine<WW>::lds_bytes(p), bytes, nbytes, stripe_base, nstripes, accept, stream)
     RRX_NFA_DISPATCH(CALL)
 #undef CALL
+}
+int match_stripes_dfa(const LineDfaDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *stripe_base, size_t nstripes,
+                      uint8_t *accept, void *stream) {
+    if (p.wide) return launch_stripes<LineDfaEngine<true>, LineDfaDevice>(p, LineDfaEngine<true>::lds_bytes(p), bytes, nbytes, stripe_base, nstripes, accept, stream);
+    return launch_stripes<LineDfaEngine<false>, LineDfaDevice>(p, LineDfaEngine<false>::lds_bytes(p), bytes, nbytes, stripe_base, nstripes, accept, stream);
 }
 int match_extents_nfa(const NfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim, uint8_t *accept,
                       void *stream) {
-#define CALL(WW) launch_extents<NfaEngine<WW>, NfaDevice>(p, NfaEngine<WW>::lds_bytes(p), bytes, off, nitems, trim, accept, stream)
+#define CALL(WW) launch_extents<PlainNfaEngine<WW>, NfaDevice>(p, PlainNfaEngine<WW>::lds_bytes(p), bytes, off, nitems, trim, accept, stream)
     RRX_NFA_DISPATCH(CALL)
 #undef CALL
 }
-int match_tiles_dfa(const DfaDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *tile_base, size_t ntiles,
-                    uint8_t *accept, void *stream) {
-    return launch_tiles<DfaEngine, DfaDevice>(p, DfaEngine::lds_bytes(p), bytes, nbytes, tile_base, ntiles, accept, stream);
-}
 int match_extents_dfa(const DfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim, uint8_t *accept,
                       void *stream) {
-    return launch_extents<DfaEngine, DfaDevice>(p, DfaEngine::lds_bytes(p), bytes, off, nitems, trim, accept, stream);
+    return launch_extents<PlainDfaEngine, DfaDevice>(p, PlainDfaEngine::lds_bytes(p), bytes, off, nitems, trim, accept, stream);
 }
 
 }  // namespace dev

@@ -12,7 +12,7 @@ from pyoracle import OracleError, OracleRegex
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
-TILE, SEG, HALO = 32768, 128, 2048
+STRIPE, ROUND, BLOCK = 4096, 64, 256 * 4096      # kernel geometry (device.hpp)
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -114,33 +114,51 @@ def _boundary_corpus(rng, total, cut_positions, alphabet=b"ab"):
     return a
 
 
-def test_lines_cut_exactly_at_segment_and_tile_boundaries():
+def test_lines_cut_exactly_at_round_stripe_and_block_boundaries():
     rng = random.Random(5)
-    total = 3 * TILE + 777
+    total = 5 * STRIPE + 777
     for delta in (-2, -1, 0, 1):
-        cuts = [k * SEG + delta for k in range(1, total // SEG + 1, 3)] + [TILE + delta, 2 * TILE + delta, 3 * TILE + delta]
+        cuts = [k * ROUND + delta for k in range(1, total // ROUND + 1, 3)] + [k * STRIPE + delta for k in range(1, 6)]
         data = _boundary_corpus(rng, total, cuts)
         check("(a|b)*abb(a|b)*", data)
-    # corpus sizes that are exact multiples of the tile, with and without a trailing newline
-    for n in (TILE, 2 * TILE):
+    # newlines ONLY at stripe boundaries (+delta): every lane starts mid-line or exactly on a line start
+    for delta in (-1, 0, 1):
+        data = _boundary_corpus(rng, 9 * STRIPE + 5, [k * STRIPE + delta for k in range(1, 10)])
+        check("(a|b)*abb(a|b)*", data)
+    # corpus sizes that are exact multiples of the stripe / of a whole workgroup, with and without trailing newline
+    for n in (STRIPE, 2 * STRIPE, BLOCK, BLOCK + STRIPE):
         data = _boundary_corpus(rng, n, range(50, n, 97))
         check("(a|b)*abb(a|b)*", data)
         data[-1] = 10
         check("(a|b)*abb(a|b)*", data)
+    # sizes that leave a partial round / partial stripe at the end
+    for n in (1, 15, 16, 63, 64, 65, STRIPE - 1, STRIPE + 1, STRIPE + 63, 3 * STRIPE + 64 + 17):
+        data = _boundary_corpus(rng, n, range(7, n, 41))
+        check("(a|b)*abb(a|b)*", data)
 
 
-def test_long_lines_through_halo_and_into_hbm():
+def test_long_lines_across_many_stripes():
     rng = random.Random(6)
     parts = []
-    for n in (SEG - 1, SEG, SEG + 1, 5 * SEG, HALO - 1, HALO, HALO + 1, HALO + SEG + 5, TILE - 1, TILE, TILE + 1, 2 * TILE + 300, 17):
+    for n in (ROUND - 1, ROUND, ROUND + 1, 5 * ROUND, STRIPE - 1, STRIPE, STRIPE + 1, STRIPE + ROUND + 5, 3 * STRIPE + 300,
+              17, 2 * STRIPE, 40 * STRIPE + 3, 5):
         body = bytes(rng.choice(b"ab") for _ in range(n))
         parts.append(body)
     data = b"\n".join(parts) + b"\n"
     check("(a|b)*abb(a|b)*", np.frombuffer(data, dtype=np.uint8))
     check("(a|b)*", np.frombuffer(data, dtype=np.uint8))
-    # one single unterminated string much longer than a tile (BASELINE config 1 shape)
-    one = np.frombuffer(bytes(rng.choice(b"abc") for _ in range(3 * TILE + 123)), dtype=np.uint8)
+    # one single unterminated string much longer than a stripe (BASELINE config 1 shape)
+    one = np.frombuffer(bytes(rng.choice(b"abc") for _ in range(7 * STRIPE + 123)), dtype=np.uint8)
     check("(a|b|c)*abc", one)
+
+
+def test_many_short_lines_overflow_the_result_register():
+    # > 16 line ends inside one 16-byte unit / > 32 inside one round: exercises the early flush
+    check("a*", b"\n" * (3 * STRIPE + 5))
+    check("a?", (b"a\n" * 40000) + b"\n\n\na")
+    rng = random.Random(8)
+    data = bytes(rng.choice(b"a\n\n") for _ in range(6 * STRIPE + 11))
+    check("a{1,3}", np.frombuffer(data, dtype=np.uint8))
 
 
 def test_ragged_random_lines_small_alphabet():
