@@ -11,7 +11,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "librrx.so")
+_SO = os.environ.get("RRX_LIB") or os.path.join(_HERE, "librrx.so")   # RRX_LIB: A/B builds of the same ABI
 
 ENGINE_AUTO, ENGINE_NFA, ENGINE_DFA = 0, 1, 2
 

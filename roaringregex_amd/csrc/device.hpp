@@ -9,7 +9,10 @@ namespace dev {
 // Geometry of the batch kernel: lane g of the grid owns the lines that START in the contiguous stripe
 // bytes [g*kStripe, (g+1)*kStripe) and follows its last line past the stripe end.  Every lane streams its
 // stripe straight from HBM into registers, kRound bytes (4 x 16 B) per round.
-constexpr int kThreads = 256;
+#ifndef RRX_THREADS
+#define RRX_THREADS 1024
+#endif
+constexpr int kThreads = RRX_THREADS;       // lanes per workgroup: one LDS copy of the tables serves them all
 constexpr int kStripe = 4096;
 constexpr int kRound = 64;
 constexpr int kMaxNfaWords = 8;                  // 256 positions per lane-resident state set
