@@ -61,9 +61,13 @@ int    rrx_corpus_create(int device, const void *d_bytes, size_t nbytes, void *s
 size_t rrx_corpus_num_lines(const rrx_corpus *c);
 size_t rrx_corpus_num_bytes(const rrx_corpus *c);
 void   rrx_corpus_free(rrx_corpus *c);
-/* THE HOT PATH.  d_accept[i] = 1 iff string i is accepted (i.e. *it has a value, regex.h:160-162; its
- * Match is then [start of string i, its terminator)).  d_accept holds rrx_corpus_num_lines() bytes.          */
-int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint8_t *d_accept, void *stream);
+size_t rrx_corpus_bitmap_words(const rrx_corpus *c);   /* 32-bit words of the accept bitmap: ceil(lines / 32) */
+/* THE HOT PATH.  Writes the accept BITMAP: bit (i & 31) of d_accept_bits[i >> 5] = 1 iff string i is accepted
+ * (i.e. *it has a value, regex.h:160-162; its Match is then [start of string i, its terminator)).
+ * d_accept_bits holds rrx_corpus_bitmap_words() words; it is zeroed and filled on `stream`.                  */
+int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accept_bits, void *stream);
+/* One byte per string (0/1) from the bitmap; d_accept holds nlines bytes, 16-byte aligned.                  */
+int rrx_bitmap_to_bytes(int device, const uint32_t *d_accept_bits, size_t nlines, uint8_t *d_accept, void *stream);
 
 /* explicit extents: item i = d_bytes[d_off[i] .. d_off[i+1] - trim); '\n' is an ordinary character here */
 int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, const uint64_t *d_off, size_t nitems,

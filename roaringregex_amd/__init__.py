@@ -20,7 +20,8 @@ ABI_SYMBOLS = (
     "rrx_compile", "rrx_compile_ex", "rrx_free", "rrx_last_error",
     "rrx_num_states", "rrx_set_class", "rrx_ref_initial", "rrx_ref_is_final", "rrx_ref_row",
     "rrx_engine", "rrx_engine_name", "rrx_useful_states", "rrx_byte_classes", "rrx_words_per_set", "rrx_program_words",
-    "rrx_corpus_create", "rrx_corpus_num_lines", "rrx_corpus_num_bytes", "rrx_corpus_free", "rrx_match_corpus",
+    "rrx_corpus_create", "rrx_corpus_num_lines", "rrx_corpus_num_bytes", "rrx_corpus_free", "rrx_corpus_bitmap_words",
+    "rrx_match_corpus", "rrx_bitmap_to_bytes",
     "rrx_match_extents", "rrx_match_host", "rrx_match_cstr",
 )
 
@@ -63,7 +64,9 @@ def _load():
         "rrx_corpus_num_lines": (sz, [vp]),
         "rrx_corpus_num_bytes": (sz, [vp]),
         "rrx_corpus_free": (None, [vp]),
+        "rrx_corpus_bitmap_words": (sz, [vp]),
         "rrx_match_corpus": (i32, [vp, vp, vp, vp]),
+        "rrx_bitmap_to_bytes": (i32, [i32, vp, sz, vp, vp]),
         "rrx_match_extents": (i32, [vp, i32, vp, vp, sz, u32, vp, vp]),
         "rrx_match_host": (i32, [vp, i32, vp, sz, vp, sz, C.POINTER(sz)]),
         "rrx_match_cstr": (i32, [vp, i32, C.c_char_p, C.POINTER(i32), C.POINTER(sz)]),
@@ -183,15 +186,29 @@ class RRegex:
         return IteratorWrapper(self, text, self.device)
 
     # ---- batch entry
+    def match_corpus_bits(self, corpus, out=None, stream=None):
+        """THE HOT PATH (rrx_match_corpus): the accept bitmap as an int32 tensor, bit (i & 31) of word i >> 5 =
+        line i accepted.  Asynchronous on `stream`."""
+        import torch
+        nw = _L.rrx_corpus_bitmap_words(corpus._h)
+        if out is None:
+            out = torch.empty(nw, dtype=torch.int32, device=corpus.data.device)
+        assert out.is_cuda and out.dtype == torch.int32 and out.numel() >= nw
+        with torch.cuda.device(corpus.device):
+            _check(_L.rrx_match_corpus(self._h, corpus._h, C.c_void_p(out.data_ptr() if nw else 0), _stream_ptr(stream)))
+        return out[:nw]
+
     def match_corpus(self, corpus, out=None, stream=None):
-        """accept[i] = 1 iff line i of the corpus is accepted.  Asynchronous on `stream`."""
+        """accept[i] = 1 iff line i of the corpus is accepted (one byte per line: bitmap + expansion)."""
         import torch
         n = corpus.num_lines
+        bits = self.match_corpus_bits(corpus, stream=stream)
         if out is None:
             out = torch.empty(n, dtype=torch.uint8, device=corpus.data.device)
         assert out.is_cuda and out.dtype == torch.uint8 and out.numel() >= n
         with torch.cuda.device(corpus.device):
-            _check(_L.rrx_match_corpus(self._h, corpus._h, C.c_void_p(out.data_ptr() if n else 0), _stream_ptr(stream)))
+            _check(_L.rrx_bitmap_to_bytes(corpus.device, C.c_void_p(bits.data_ptr() if n else 0), n,
+                                          C.c_void_p(out.data_ptr() if n else 0), _stream_ptr(stream)))
         return out[:n]
 
     def match_extents(self, data, offsets, trim=0, out=None, stream=None):

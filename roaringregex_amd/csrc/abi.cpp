@@ -82,8 +82,8 @@ struct rrx_regex {
             oN = put(dfa.next.data(), dfa.next.size() * 2);
             oA = put(dfa.accepting.data(), dfa.accepting.size());
             t.dfa.nstates = dfa.nstates; t.dfa.ncls = dfa.ncls; t.dfa.start = dfa.start;
-            // line-mode table: entry = next row byte offset | nl << 30 | accept << 31; the '\n' column of every row
-            // goes to the start row and carries the verdict of the line that just ended.
+            // line-mode table: entry = next row byte offset (16 bits) | nl << 16 | accept << 24; the '\n' column of
+            // every row goes to the start row and carries the verdict of the line that just ended.
             const uint32_t D = dfa.nstates, K = dfa.ncls;
             const bool wide = line_wide;
             uint32_t stride = wide ? dev::kWideColumns : (K + 1);
@@ -95,7 +95,7 @@ struct rrx_regex {
             const uint32_t row_bytes = stride * 4;
             for (uint32_t d = 0; d < D; d++) {
                 uint32_t *row = &T[(size_t)d * stride];
-                const uint32_t nl_entry = dfa.start * row_bytes | 1u << 30 | (dfa.accepting[d] ? 1u << 31 : 0u);
+                const uint32_t nl_entry = dfa.start * row_bytes | 1u << 16 | (dfa.accepting[d] ? 1u << 24 : 0u);
                 if (wide) {
                     for (uint32_t c = 0; c < 128; c++) row[c] = (uint32_t)dfa.next[(size_t)d * K + dfa.cls[c]] * row_bytes;
                     row['\n'] = nl_entry;
@@ -132,8 +132,9 @@ struct rrx_corpus {
     int device = 0;
     const uint8_t *d_bytes = nullptr;
     size_t nbytes = 0, nstripes = 0, nlines = 0;
-    uint32_t *d_counts = nullptr;
-    uint64_t *d_base = nullptr;
+    uint32_t *d_counts = nullptr;   // [nstripes] newlines per stripe, then one flags word
+    uint64_t *d_base = nullptr;     // [nstripes+1] exclusive prefix
+    bool has_high = false;          // some byte >= 0x80 occurs
 };
 
 extern "C" {
@@ -154,8 +155,8 @@ int rrx_compile_ex(const char *pattern, int engine, rrx_regex **out) {
             re->has_dfa = lower_dfa(re->trimmed, kMaxSubsetStates, re->dfa);
             if (re->has_dfa) {
                 re->line_wide = re->dfa.nstates <= dev::kWideMaxStates;
-                const size_t classed = (size_t)re->dfa.nstates * (re->dfa.ncls + 2) * 4 + 256;
-                if (!re->line_wide && classed > dev::kClassedLdsBudget) re->has_dfa = false;
+                const size_t classed_entries = (size_t)re->dfa.nstates * (re->dfa.ncls + 2);
+                if (!re->line_wide && classed_entries > dev::kClassedMaxEntries) re->has_dfa = false;
             }
         }
     } catch (const PatternError &e) {
@@ -227,15 +228,21 @@ int rrx_corpus_create(int device, const void *d_bytes, size_t nbytes, void *stre
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->d_counts), (c->nstripes + 1) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_base), (c->nstripes + 1) * sizeof(uint64_t));
     if (e != hipSuccess) { rrx_corpus_free(c); return hip_fail(e, "hipMalloc(line index)"); }
-    int rc = dev::count_newlines_per_stripe(c->d_bytes, nbytes, c->d_counts, c->nstripes, stream);
+    uint32_t *d_flags = c->d_counts + c->nstripes;
+    e = hipMemsetAsync(d_flags, 0, sizeof(uint32_t), (hipStream_t)stream);
+    if (e != hipSuccess) { rrx_corpus_free(c); return hip_fail(e, "hipMemsetAsync(flags)"); }
+    int rc = dev::count_newlines_per_stripe(c->d_bytes, nbytes, c->d_counts, c->nstripes, d_flags, stream);
     if (!rc) rc = dev::scan_counts(c->d_counts, c->d_base, c->nstripes, stream);
     if (rc) { rrx_corpus_free(c); return hip_fail((hipError_t)rc, "line index launch"); }
     uint64_t total = 0;
+    uint32_t flags = 0;
     uint8_t last = '\n';
     e = hipMemcpyAsync(&total, c->d_base + c->nstripes, sizeof total, hipMemcpyDeviceToHost, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&flags, d_flags, sizeof flags, hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess && nbytes) e = hipMemcpyAsync(&last, c->d_bytes + nbytes - 1, 1, hipMemcpyDeviceToHost, (hipStream_t)stream);
     if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) { rrx_corpus_free(c); return hip_fail(e, "line index readback"); }
+    c->has_high = (flags & 1u) != 0;
     c->nlines = (size_t)total + ((nbytes && last != '\n') ? 1 : 0);
     *out = c;
     return RRX_OK;
@@ -250,16 +257,30 @@ void rrx_corpus_free(rrx_corpus *c) {
     delete c;
 }
 
-int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint8_t *d_accept, void *stream) {
-    if (!re || !c || (c->nlines && !d_accept)) return fail(RRX_ERR_ARG, "null argument");
+size_t rrx_corpus_bitmap_words(const rrx_corpus *c) { return (c->nlines + 31) / 32; }
+
+int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accept_bits, void *stream) {
+    if (!re || !c || (c->nlines && !d_accept_bits)) return fail(RRX_ERR_ARG, "null argument");
     const DeviceTables *t;
     int rc = re->tables(c->device, &t);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
+    if (!c->nlines) return RRX_OK;
+    // the kernel merges words with atomic OR: start from an all-zero bitmap
+    HIP_TRY(hipMemsetAsync(d_accept_bits, 0, rrx_corpus_bitmap_words(c) * sizeof(uint32_t), (hipStream_t)stream));
     int e = re->engine == RRX_ENGINE_NFA
-                ? dev::match_stripes_nfa(t->nfa, c->d_bytes, c->nbytes, c->d_base, c->nstripes, d_accept, stream)
-                : dev::match_stripes_dfa(t->line, c->d_bytes, c->nbytes, c->d_base, c->nstripes, d_accept, stream);
+                ? dev::match_stripes_nfa(t->nfa, c->d_bytes, c->nbytes, c->d_base, c->nstripes, d_accept_bits, stream)
+                : dev::match_stripes_dfa(t->line, c->has_high, c->d_bytes, c->nbytes, c->d_base, c->nstripes, d_accept_bits, stream);
     if (e) return hip_fail((hipError_t)e, "match_stripes launch");
+    return RRX_OK;
+}
+
+int rrx_bitmap_to_bytes(int device, const uint32_t *d_bits, size_t nlines, uint8_t *d_accept, void *stream) {
+    if (nlines && (!d_bits || !d_accept)) return fail(RRX_ERR_ARG, "null argument");
+    if (reinterpret_cast<uintptr_t>(d_accept) & 15) return fail(RRX_ERR_ARG, "byte buffer must be 16-byte aligned");
+    HIP_TRY(hipSetDevice(device));
+    int e = dev::expand_bits(d_bits, nlines, d_accept, stream);
+    if (e) return hip_fail((hipError_t)e, "expand_bits launch");
     return RRX_OK;
 }
 
@@ -288,17 +309,21 @@ int rrx_match_host(const rrx_regex *re, int device, const void *bytes, size_t nb
     if (e == hipSuccess && nbytes) e = hipMemcpy(d_bytes, bytes, nbytes, hipMemcpyHostToDevice);
     if (e != hipSuccess) rc = hip_fail(e, "corpus upload");
     if (!rc) rc = rrx_corpus_create(device, d_bytes, nbytes, nullptr, &c);
+    uint32_t *d_bits = nullptr;
     if (!rc) {
         *nlines = c->nlines;
-        e = hipMalloc(reinterpret_cast<void **>(&d_acc), c->nlines + 16);
+        e = hipMalloc(reinterpret_cast<void **>(&d_acc), c->nlines + 64);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_bits), (rrx_corpus_bitmap_words(c) + 4) * sizeof(uint32_t));
         if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(accept)");
     }
-    if (!rc) rc = rrx_match_corpus(re, c, d_acc, nullptr);
+    if (!rc) rc = rrx_match_corpus(re, c, d_bits, nullptr);
+    if (!rc) rc = rrx_bitmap_to_bytes(device, d_bits, c->nlines, d_acc, nullptr);
     if (!rc) {
         size_t n = c->nlines < cap ? c->nlines : cap;
         e = hipMemcpy(accept, d_acc, n, hipMemcpyDeviceToHost);    // synchronises with the default stream
         if (e != hipSuccess) rc = hip_fail(e, "accept readback");
     }
+    if (d_bits) (void)hipFree(d_bits);
     if (c) rrx_corpus_free(c);
     if (d_acc) (void)hipFree(d_acc);
     if (d_bytes) (void)hipFree(d_bytes);

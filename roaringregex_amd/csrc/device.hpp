@@ -8,17 +8,17 @@ namespace dev {
 
 // Geometry of the batch kernel: lane g of the grid owns the lines that START in the contiguous stripe
 // bytes [g*kStripe, (g+1)*kStripe) and follows its last line past the stripe end.  Every lane streams its
-// stripe straight from HBM into registers, kRound bytes (4 x 16 B) per round.
+// stripe straight from HBM into registers, kRound bytes (8 x 16 B) per round.
 #ifndef RRX_THREADS
 #define RRX_THREADS 1024
 #endif
 constexpr int kThreads = RRX_THREADS;       // lanes per workgroup: one LDS copy of the tables serves them all
 constexpr int kStripe = 4096;
-constexpr int kRound = 64;
+constexpr int kRound = 128;                      // one whole cache line per lane per round
 constexpr int kMaxNfaWords = 8;                  // 256 positions per lane-resident state set
 constexpr uint32_t kWideColumns = 129;           // columns 0..127 = byte values, 128 = any byte >= 0x80
 constexpr uint32_t kWideMaxStates = 127;         // row byte offsets must fit 16 bits
-constexpr uint32_t kClassedLdsBudget = 120 * 1024;
+constexpr uint32_t kClassedMaxEntries = 16384;   // row byte offsets are 16-bit: 64 KiB of 4-byte entries
 
 struct NfaMasks {                                // passed by value -> SGPRs
     uint32_t init[kMaxNfaWords], fin[kMaxNfaWords], chain[kMaxNfaWords], self[kMaxNfaWords], excm[kMaxNfaWords];
@@ -40,7 +40,7 @@ struct DfaDevice {
 };
 
 // Line-mode DFA tables (batch kernel): the '\n' transition of every row goes to the start row and carries
-// the verdict of the line that just ended.  Entry = next row byte offset | nl << 30 | accept << 31.
+// the verdict of the line that just ended.  Entry = next row byte offset (16 bits) | nl << 16 | accept << 24.
 struct LineDfaDevice {
     uint32_t nrows = 0;                          // rows (row 0 = dead)
     uint32_t stride = 0;                         // entries per row
@@ -51,13 +51,15 @@ struct LineDfaDevice {
 };
 
 // All launchers are asynchronous on `stream` and return a hipError_t value (0 = success).
-int count_newlines_per_stripe(const uint8_t *bytes, size_t nbytes, uint32_t *counts, size_t nstripes, void *stream);
+int count_newlines_per_stripe(const uint8_t *bytes, size_t nbytes, uint32_t *counts, size_t nstripes, uint32_t *flags, void *stream);
 int scan_counts(const uint32_t *counts, uint64_t *base, size_t n, void *stream);
+int expand_bits(const uint32_t *bits, size_t nlines, uint8_t *out, void *stream);
 
+// accept_bits: bitmap, bit i = line i accepted; must be zeroed before the launch (the launchers do not)
 int match_stripes_nfa(const NfaDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *stripe_base,
-                      size_t nstripes, uint8_t *accept, void *stream);
-int match_stripes_dfa(const LineDfaDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *stripe_base,
-                      size_t nstripes, uint8_t *accept, void *stream);
+                      size_t nstripes, uint32_t *accept_bits, void *stream);
+int match_stripes_dfa(const LineDfaDevice &p, bool clamp_high, const uint8_t *bytes, size_t nbytes, const uint64_t *stripe_base,
+                      size_t nstripes, uint32_t *accept_bits, void *stream);
 
 // items i = bytes[off[i] .. off[i+1] - trim) ; trim = 1 drops a trailing delimiter byte per item
 int match_extents_nfa(const NfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim,

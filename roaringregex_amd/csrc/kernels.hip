@@ -9,16 +9,23 @@
 // Batch kernel (match_stripes<Engine>) — the text never touches LDS:
 //   * lane g of the grid owns the lines that START in its contiguous 4 KiB stripe of the corpus and follows
 //     its last line past the stripe end, so every line is stepped by exactly one lane from its first byte;
-//   * each lane streams its own stripe from HBM straight into registers, 64 bytes (4 x global_load_dwordx4)
-//     per round, the next round's loads in flight while the current one is stepped (measured: this per-lane
-//     streaming pattern reads at the same 6.3-6.4 TB/s as a fully coalesced copy, profiles/r01_membench*);
+//   * each lane streams its own stripe from HBM straight into registers, one whole 128-byte line
+//     (8 x global_load_dwordx4) per round through a rotating 8-slot register buffer: slot i is refilled for
+//     the next round right after it has been consumed, so every fetched line is used up while it is still
+//     resident (a 64-byte round re-fetched the second half of every line: measured 1.73x read traffic);
 //   * the automaton tables live in LDS, the state lives in registers;
-//   * line results are accumulated in a register as ordered bits and flushed once per round as byte stores
-//     accept[line]; line = stripe_base[g] + newlines seen so far, stripe_base being the per-stripe newline
-//     prefix the corpus carries (8 bytes per 4 KiB of text): no per-line offset array is ever read.
+//   * line verdicts are accumulated in registers as ordered bits, packed into the lane's current 32-bit
+//     output word and merged into the accept BITMAP (bit i = line i) with one global atomic OR per filled
+//     word (about one per 32 lines; per-line byte stores cost 23x their size in HBM write traffic);
+//     line index = stripe_base[g] + newlines seen so far, stripe_base being the per-stripe newline prefix
+//     the corpus carries (8 bytes per 4 KiB of text): no per-line offset array is ever read.
 #include <hip/hip_runtime.h>
 
 #include "device.hpp"
+
+#ifndef RRX_FEED
+#define RRX_FEED 3
+#endif
 
 namespace rrx {
 namespace dev {
@@ -32,9 +39,11 @@ namespace {
 //                                           line it ended (valid when nl)
 
 // ---- wide / classed table DFA: '\n' handling folded into the table -------------------------------
-template <bool WIDE>
+template <bool WIDE, bool CLAMP>
 struct LineDfaEngine {
-    struct State { uint32_t e; };          // last table entry; low 30 bits = current row byte offset
+    // Table entry: bits 0..15 = byte offset of the next row, byte 2 = 1 iff the consumed byte was '\n',
+    // byte 3 = verdict of the line it ended.  (16-bit entries read with ds_read_u16 measured 3-4 % slower.)
+    struct State { uint32_t e; };
     const uint8_t *tab;                    // LDS, byte-addressed
     const uint8_t *cls;                    // LDS [256] (classed form)
     uint32_t start_off;
@@ -56,12 +65,12 @@ struct LineDfaEngine {
     __device__ __forceinline__ State skipping() const { return State{0}; }          // dead row: waits for '\n'
     __device__ __forceinline__ void step(State &st, uint32_t c, uint32_t &nl, uint32_t &acc) const {
         uint32_t col;
-        if (WIDE) col = c < 128u ? c : 128u;
+        if (WIDE) col = CLAMP ? (c < 128u ? c : 128u) : c;      // !CLAMP: the corpus holds no byte >= 0x80
         else col = cls[c];
-        const uint32_t off = (st.e & 0x3fffffffu) + col * 4u;
+        const uint32_t off = (st.e & 0xffffu) + (col << 2);
         st.e = *reinterpret_cast<const uint32_t *>(tab + off);
-        nl = (st.e >> 30) & 1u;
-        acc = st.e >> 31;
+        nl = (st.e >> 16) & 0xffu;
+        acc = st.e >> 24;
     }
 };
 
@@ -189,44 +198,53 @@ struct PlainDfaEngine {
 };
 
 // ============================================================================================ batch kernel
-// Ordered line results of one lane: `bits` holds a sentinel 1 followed by one verdict bit per finished line
-// (oldest highest).  flush() stores them as bytes accept[line++]; the first result of a lane that started
-// inside somebody else's line belongs to that somebody and is dropped (it is still counted).
+// Line verdicts of one lane.  `bits` = sentinel 1 followed by one verdict bit per line finished since the
+// last flush (oldest highest).  flush() appends them, oldest first, to the lane's current output word at bit
+// position `fill` and ORs every completed word into the accept bitmap (bit i of the bitmap = line i).
+// The first result of a lane that started inside somebody else's line belongs to that somebody (who reports
+// it when it follows the line past its own stripe): its bit is skipped but its index is consumed.
 struct Results {
     uint32_t bits = 1;
-    uint64_t line;
+    uint32_t outw = 0;
+    uint32_t fill;
+    uint32_t seen = 0;
+    uint64_t word;
     bool drop_first;
-    uint8_t *__restrict__ accept;
+    uint32_t *__restrict__ out;
 
+    __device__ __forceinline__ void begin(uint64_t first_line, bool drop, uint32_t *bitmap) {
+        word = first_line >> 5; fill = (uint32_t)first_line & 31u; drop_first = drop; out = bitmap;
+    }
     __device__ __forceinline__ void push(uint32_t nl, uint32_t acc) { bits = (bits << nl) | acc; }
     __device__ __forceinline__ void flush() {
-        int n = 31 - __clz((int)bits);
-        while (__any(n > 0)) {
-            if (n > 0) {
-                n--;
-                if (drop_first) drop_first = false;
-                else accept[line] = (uint8_t)((bits >> n) & 1u);
-                line++;
+        const int n = 31 - __clz((int)bits);
+        if (n > 0) {                                         // n <= 31: callers flush before bits can overflow
+            uint32_t rev = __brev(bits & ((1u << n) - 1u)) >> (32 - n);      // oldest line at bit 0
+            if (drop_first) { rev &= ~1u; drop_first = false; }
+            outw |= rev << fill;
+            uint32_t nf = fill + (uint32_t)n;
+            if (nf >= 32u) {                                 // then fill >= 1
+                if (outw) atomicOr(&out[word], outw);
+                word++;
+                outw = rev >> (32u - fill);
+                nf -= 32u;
             }
+            fill = nf;
+            seen += (uint32_t)n;
+            bits = 1;
         }
-        bits = 1;
     }
-    // same, for code that runs with lanes diverged (no wave-wide vote)
-    __device__ __forceinline__ void flush_lane() {
-        for (int n = 31 - __clz((int)bits); n > 0;) {
-            n--;
-            if (drop_first) drop_first = false;
-            else accept[line] = (uint8_t)((bits >> n) & 1u);
-            line++;
-        }
-        bits = 1;
+    __device__ __forceinline__ void finish() {
+        flush();
+        if (outw) atomicOr(&out[word], outw);
+        outw = 0;
     }
 };
 
 template <class Engine, class Program>
 __global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, const uint8_t *__restrict__ bytes, size_t nbytes,
                                                                   const uint64_t *__restrict__ stripe_base,
-                                                                  uint8_t *__restrict__ accept) {
+                                                                  uint32_t *__restrict__ accept_bits) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     Engine eng;
     eng.load(prog, smem);
@@ -240,39 +258,68 @@ __global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, c
     const bool fresh = start == 0 || bytes[start - 1] == '\n';
     typename Engine::State st = fresh ? eng.fresh() : eng.skipping();
     Results res;
-    res.line = stripe_base[g];
-    res.drop_first = !fresh;
-    res.accept = accept;
-    const uint64_t first_line = res.line;
+    res.begin(stripe_base[g], !fresh, accept_bits);
 
-    // ---- main phase: whole 64-byte rounds of my stripe, next round's loads in flight
+    // ---- main phase: whole 128-byte rounds of my stripe.  RRX_FEED selects how the next line is requested:
+    //   0  rotating: slot i is refilled right after it has been consumed (8 separate requests per line)
+    //   1  burst: all 8 loads of the next line are issued together at the start of the round
+    //   2  split burst: 4 loads at the start of the round, the other 4 one unit later
+    //   3  single buffer: the burst for the next line is issued after the current one has been consumed
+    //      (no register double buffer: other waves of the SIMD cover the fetch)
     size_t pos = start;
     const uint4 *src = reinterpret_cast<const uint4 *>(bytes + start);
+    constexpr int kSlots = kRound / 16;
     const int rounds = (int)((my_end - start) / kRound);
-    uint4 cur[4], nxt[4];
+    uint4 buf[kSlots];
+#if RRX_FEED == 1 || RRX_FEED == 2
+    uint4 nxt[kSlots];
+#endif
     if (rounds > 0) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) cur[i] = src[i];
+        for (int i = 0; i < kSlots; i++) buf[i] = src[i];
     }
     for (int r = 0; r < rounds; r++) {
-        if (r + 1 < rounds) {
+        const bool more = r + 1 < rounds;
+#if RRX_FEED == 1
+        if (more) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) nxt[i] = src[(r + 1) * 4 + i];
+            for (int i = 0; i < kSlots; i++) nxt[i] = src[(r + 1) * kSlots + i];
         }
+#elif RRX_FEED == 2
+        if (more) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const uint32_t w[4] = {cur[i].x, cur[i].y, cur[i].z, cur[i].w};
+            for (int i = 0; i < kSlots / 2; i++) nxt[i] = src[(r + 1) * kSlots + i];
+        }
+#endif
+#pragma unroll
+        for (int i = 0; i < kSlots; i++) {
+            const uint32_t w[4] = {buf[i].x, buf[i].y, buf[i].z, buf[i].w};
+#if RRX_FEED == 0
+            if (more) buf[i] = src[(r + 1) * kSlots + i];
+#elif RRX_FEED == 2
+            if (i == 1 && more) {
+#pragma unroll
+                for (int j = kSlots / 2; j < kSlots; j++) nxt[j] = src[(r + 1) * kSlots + j];
+            }
+#endif
 #pragma unroll
             for (int k = 0; k < 16; k++) {
                 uint32_t nl, acc;
                 eng.step(st, (w[k >> 2] >> (8 * (k & 3))) & 0xffu, nl, acc);
                 res.push(nl, acc);
             }
-            if (__any(res.bits >> 15)) res.flush();      // <= 16 more results fit before the next check
+            if (res.bits >> 15) res.flush();                 // <= 16 more results fit before the next check
         }
         res.flush();
+#if RRX_FEED == 1 || RRX_FEED == 2
 #pragma unroll
-        for (int i = 0; i < 4; i++) cur[i] = nxt[i];
+        for (int i = 0; i < kSlots; i++) buf[i] = nxt[i];
+#elif RRX_FEED == 3
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < kSlots; i++) buf[i] = src[(r + 1) * kSlots + i];
+        }
+#endif
     }
     pos += (size_t)rounds * kRound;
 
@@ -281,20 +328,20 @@ __global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, c
         uint32_t nl, acc;
         eng.step(st, bytes[pos], nl, acc);
         res.push(nl, acc);
-        if (res.bits >> 30) res.flush_lane();
+        if (res.bits >> 30) res.flush();
     }
-    res.flush_lane();
+    res.flush();
 
     // ---- follow my last line past the stripe end.  It is mine iff I started it: I began at a line start or
     // saw a '\n' inside my stripe, and my stripe does not end exactly on a '\n'.
-    const bool started = fresh || res.line > first_line;
+    const bool started = fresh || res.seen > 0;
     if (started && bytes[my_end - 1] != '\n') {
         uint32_t nl = 0, acc = 0;
         for (; pos < nbytes && !nl; pos++) eng.step(st, bytes[pos], nl, acc);
         if (!nl) eng.step(st, '\n', nl, acc);       // the corpus ends without '\n': end of data ends the line
         res.push(nl, acc);
-        res.flush_lane();
     }
+    res.finish();
 }
 
 // ============================================================================================ extents kernel
@@ -323,34 +370,58 @@ __global__ __launch_bounds__(kThreads) void match_extents_kernel(Program prog, c
 }
 
 // ============================================================================================ line index
-// counts[g] = number of '\n' in stripe g, streamed exactly like the match kernel streams it.
-__global__ __launch_bounds__(kThreads) void count_newlines_kernel(const uint8_t *__restrict__ bytes, size_t nbytes,
-                                                                   uint32_t *__restrict__ counts, size_t nstripes) {
-    const size_t g = (size_t)blockIdx.x * kThreads + threadIdx.x;
+// counts[g] = number of '\n' in stripe g, streamed exactly like the match kernel streams it.  Also raises
+// *flags bit 0 if any byte >= 0x80 occurs (the match kernel then clamps such bytes to the dead column).
+__global__ __launch_bounds__(256) void count_newlines_kernel(const uint8_t *__restrict__ bytes, size_t nbytes,
+                                                              uint32_t *__restrict__ counts, size_t nstripes,
+                                                              uint32_t *__restrict__ flags) {
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= nstripes) return;
     const size_t start = g * (size_t)kStripe;
     const size_t end = start + kStripe < nbytes ? start + kStripe : nbytes;
     const uint4 *src = reinterpret_cast<const uint4 *>(bytes + start);
     const int units = (int)((end - start) / 16);
-    uint32_t cnt = 0;
+    uint32_t cnt = 0, high = 0;
     int u = 0;
-    for (; u + 4 <= units; u += 4) {
-        uint4 v[4];
+    for (; u + 8 <= units; u += 8) {
+        uint4 v[8];
 #pragma unroll
-        for (int i = 0; i < 4; i++) v[i] = src[u + i];
+        for (int i = 0; i < 8; i++) v[i] = src[u + i];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
+        for (int i = 0; i < 8; i++) {
             const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 uint32_t x = w[j] ^ 0x0a0a0a0au;                                        // zero byte <=> '\n'
                 uint32_t z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);    // exact zero-byte test
                 cnt += __popc(z);
+                high |= w[j];
             }
         }
     }
-    for (size_t p = start + (size_t)u * 16; p < end; p++) cnt += bytes[p] == '\n';
+    for (size_t p = start + (size_t)u * 16; p < end; p++) { cnt += bytes[p] == '\n'; high |= bytes[p]; }
     counts[g] = cnt;
+    if (high & 0x80808080u) atomicOr(flags, 1u);
+}
+
+// bytes[i] = bit i of the accept bitmap (the byte-per-line form of the result)
+__global__ __launch_bounds__(256) void expand_bits_kernel(const uint32_t *__restrict__ bits, size_t nlines, uint8_t *__restrict__ out) {
+    const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;          // one 32-line word -> 32 bytes
+    if (w * 32 >= nlines) return;
+    const uint32_t v = bits[w];
+    if (w * 32 + 32 <= nlines) {
+        uint4 o[2];
+        uint32_t *p = reinterpret_cast<uint32_t *>(o);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t n = (v >> (4 * j)) & 0xfu;
+            p[j] = (n & 1u) | ((n & 2u) << 7) | ((n & 4u) << 14) | ((n & 8u) << 21);
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(out + w * 32);
+        dst[0] = o[0]; dst[1] = o[1];
+    } else {
+        for (size_t i = w * 32; i < nlines; i++) out[i] = (uint8_t)((v >> (i & 31)) & 1u);
+    }
 }
 
 // exclusive scan of n counts into n+1 bases (single workgroup, chunked)
@@ -374,7 +445,7 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t *__res
 
 template <class Engine, class Program>
 int launch_stripes(const Program &p, size_t table_bytes, const uint8_t *bytes, size_t nbytes, const uint64_t *stripe_base,
-                   size_t nstripes, uint8_t *accept, void *stream) {
+                   size_t nstripes, uint32_t *accept, void *stream) {
     if (!nstripes) return 0;
     auto k = match_stripes_kernel<Engine, Program>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)table_bytes);
@@ -398,10 +469,16 @@ int launch_extents(const Program &p, size_t table_bytes, const uint8_t *bytes, c
 
 }  // namespace
 
-int count_newlines_per_stripe(const uint8_t *bytes, size_t nbytes, uint32_t *counts, size_t nstripes, void *stream) {
+int count_newlines_per_stripe(const uint8_t *bytes, size_t nbytes, uint32_t *counts, size_t nstripes, uint32_t *flags, void *stream) {
     if (!nstripes) return 0;
-    size_t blocks = (nstripes + kThreads - 1) / kThreads;
-    hipLaunchKernelGGL(count_newlines_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, bytes, nbytes, counts, nstripes);
+    size_t blocks = (nstripes + 255) / 256;
+    hipLaunchKernelGGL(count_newlines_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, bytes, nbytes, counts, nstripes, flags);
+    return (int)hipGetLastError();
+}
+int expand_bits(const uint32_t *bits, size_t nlines, uint8_t *out, void *stream) {
+    if (!nlines) return 0;
+    size_t words = (nlines + 31) / 32, blocks = (words + 255) / 256;
+    hipLaunchKernelGGL(expand_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, bits, nlines, out);
     return (int)hipGetLastError();
 }
 int scan_counts(const uint32_t *counts, uint64_t *base, size_t n, void *stream) {
@@ -422,15 +499,17 @@ int scan_counts(const uint32_t *counts, uint64_t *base, size_t n, void *stream) 
 
 // The device tables are padded to the instantiated width by the caller (NfaDevice::W is the padded width).
 int match_stripes_nfa(const NfaDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *stripe_base, size_t nstripes,
-                      uint8_t *accept, void *stream) {
+                      uint32_t *accept, void *stream) {
 #define CALL(WW) launch_stripes<LineNfaEngine<WW>, NfaDevice>(p, LineNfaEngine<WW>::lds_bytes(p), bytes, nbytes, stripe_base, nstripes, accept, stream)
     RRX_NFA_DISPATCH(CALL)
 #undef CALL
 }
-int match_stripes_dfa(const LineDfaDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *stripe_base, size_t nstripes,
-                      uint8_t *accept, void *stream) {
-    if (p.wide) return launch_stripes<LineDfaEngine<true>, LineDfaDevice>(p, LineDfaEngine<true>::lds_bytes(p), bytes, nbytes, stripe_base, nstripes, accept, stream);
-    return launch_stripes<LineDfaEngine<false>, LineDfaDevice>(p, LineDfaEngine<false>::lds_bytes(p), bytes, nbytes, stripe_base, nstripes, accept, stream);
+int match_stripes_dfa(const LineDfaDevice &p, bool clamp_high, const uint8_t *bytes, size_t nbytes, const uint64_t *stripe_base,
+                      size_t nstripes, uint32_t *accept, void *stream) {
+#define GO(WIDE, CLAMP) launch_stripes<LineDfaEngine<WIDE, CLAMP>, LineDfaDevice>(p, LineDfaEngine<WIDE, CLAMP>::lds_bytes(p), bytes, nbytes, stripe_base, nstripes, accept, stream)
+    if (p.wide) return clamp_high ? GO(true, true) : GO(true, false);
+    return GO(false, false);
+#undef GO
 }
 int match_extents_nfa(const NfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim, uint8_t *accept,
                       void *stream) {
