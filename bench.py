@@ -42,12 +42,31 @@ def patterns():
     return {"U2": u2, "EMAIL": r"[A-Za-z0-9._]+@[A-Za-z0-9.]+"}
 
 
+def host_cores():
+    """CPU share of this process: the cgroup quota if there is one, else the affinity mask, capped at 16
+    (a one-GPU box hands out 16 cores even though it shows all of the host's)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return max(1, min(n, 16))
+
+
 def cpu_baseline(pattern, host, target_seconds=12.0):
     """The oracle (CPU port of the reference's loop, NFA.cc:86-100) on a bounded sample of the same corpus,
     one oracle instance per thread (the reference is not re-entrant either), all host cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from pyoracle import OracleRegex
-    cores = max(1, len(os.sched_getaffinity(0)))
+    cores = host_cores()
     chunk = 1 << 20                                    # corpus chunks end with '\n': line-aligned slices
     # calibrate on 4 MiB, then size the sample for ~target_seconds
     o = OracleRegex(pattern)
@@ -111,7 +130,7 @@ def main():
 
     # ---- synthetic shard of this rank (seed differs per rank), generated on the host cores, then resident in HBM
     t0 = time.perf_counter()
-    threads = max(1, len(os.sched_getaffinity(0)) // max(1, world))
+    threads = max(1, min(len(os.sched_getaffinity(0)), 64) // max(1, world))
     host = np.empty(nbytes, dtype=np.uint8)
     synth.fill(kind, 2 + 1000 * rank, host, threads=threads)
     gen_s = time.perf_counter() - t0

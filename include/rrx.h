@@ -49,6 +49,7 @@ const char *rrx_engine_name(const rrx_regex *re);
 uint32_t    rrx_useful_states(const rrx_regex *re);
 uint32_t    rrx_byte_classes(const rrx_regex *re);
 uint32_t    rrx_words_per_set(const rrx_regex *re); /* 32-bit words of the register-resident state set (NFA) */
+int         rrx_accepts_empty(const rrx_regex *re); /* Processor::operator*() on the initial set, NFA.cc:103-107 */
 /* Serialised device program as 32-bit words (layout: DESIGN.md "Device programs"); returns the word count
  * (call with cap = 0 to size the buffer).  kind = RRX_ENGINE_NFA / RRX_ENGINE_DFA; 0 if that form was not built. */
 size_t rrx_program_words(const rrx_regex *re, int kind, uint32_t *out, size_t cap);

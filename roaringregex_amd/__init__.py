@@ -19,7 +19,8 @@ ENGINE_AUTO, ENGINE_NFA, ENGINE_DFA = 0, 1, 2
 ABI_SYMBOLS = (
     "rrx_compile", "rrx_compile_ex", "rrx_free", "rrx_last_error",
     "rrx_num_states", "rrx_set_class", "rrx_ref_initial", "rrx_ref_is_final", "rrx_ref_row",
-    "rrx_engine", "rrx_engine_name", "rrx_useful_states", "rrx_byte_classes", "rrx_words_per_set", "rrx_program_words",
+    "rrx_engine", "rrx_engine_name", "rrx_useful_states", "rrx_byte_classes", "rrx_words_per_set", "rrx_accepts_empty",
+    "rrx_program_words",
     "rrx_corpus_create", "rrx_corpus_num_lines", "rrx_corpus_num_bytes", "rrx_corpus_free", "rrx_corpus_bitmap_words",
     "rrx_match_corpus", "rrx_bitmap_to_bytes",
     "rrx_match_extents", "rrx_match_host", "rrx_match_cstr",
@@ -59,6 +60,7 @@ def _load():
         "rrx_useful_states": (u32, [vp]),
         "rrx_byte_classes": (u32, [vp]),
         "rrx_words_per_set": (u32, [vp]),
+        "rrx_accepts_empty": (i32, [vp]),
         "rrx_program_words": (sz, [vp, i32, vp, sz]),
         "rrx_corpus_create": (i32, [i32, vp, sz, vp, C.POINTER(vp)]),
         "rrx_corpus_num_lines": (sz, [vp]),
@@ -150,7 +152,7 @@ class Corpus:
                                         _stream_ptr(stream), C.byref(self._h)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _L is not None:      # (_L is None during interpreter shutdown)
             _L.rrx_corpus_free(self._h)
             self._h = None
 
@@ -175,7 +177,7 @@ class RRegex:
         _check(_L.rrx_compile_ex(pattern, engine, C.byref(self._h)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and _L is not None:
             _L.rrx_free(self._h)
             self._h = None
 
@@ -289,8 +291,4 @@ class RRegex:
 
     @property
     def accepts_empty(self):
-        for kind in (ENGINE_NFA, ENGINE_DFA):
-            p = self.program(kind)
-            if p is not None:
-                return bool(p[3])
-        return False
+        return bool(_L.rrx_accepts_empty(self._h))

@@ -34,7 +34,7 @@ struct DeviceTables {
     dev::LineDfaDevice line;     // line-mode form (batch kernel)
 };
 
-int instantiated_width(uint32_t W) { return W <= 4 ? (int)W : W <= 6 ? 6 : 8; }
+int instantiated_width(uint32_t W) { return W <= 4 ? (int)W : W <= 6 ? 6 : W <= 8 ? 8 : W <= 12 ? 12 : 16; }
 
 }  // namespace
 
@@ -197,6 +197,7 @@ const char *rrx_engine_name(const rrx_regex *re) {
 uint32_t rrx_useful_states(const rrx_regex *re) { return re->trimmed.n; }
 uint32_t rrx_byte_classes(const rrx_regex *re) { return re->trimmed.ncls; }
 uint32_t rrx_words_per_set(const rrx_regex *re) { return re->has_nfa ? re->nfa.W : 0; }
+int rrx_accepts_empty(const rrx_regex *re) { return re->has_nfa ? re->nfa.accepts_empty : re->dfa.accepts_empty; }
 
 size_t rrx_program_words(const rrx_regex *re, int kind, uint32_t *out, size_t cap) {
     std::vector<uint32_t> w;

@@ -15,7 +15,7 @@ namespace dev {
 constexpr int kThreads = RRX_THREADS;       // lanes per workgroup: one LDS copy of the tables serves them all
 constexpr int kStripe = 4096;
 constexpr int kRound = 128;                      // one whole cache line per lane per round
-constexpr int kMaxNfaWords = 8;                  // 256 positions per lane-resident state set
+constexpr int kMaxNfaWords = 16;                 // 512 positions per lane-resident state set
 constexpr uint32_t kWideColumns = 129;           // columns 0..127 = byte values, 128 = any byte >= 0x80
 constexpr uint32_t kWideMaxStates = 127;         // row byte offsets must fit 16 bits
 constexpr uint32_t kClassedMaxEntries = 16384;   // row byte offsets are 16-bit: 64 KiB of 4-byte entries

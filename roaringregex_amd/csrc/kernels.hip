@@ -494,6 +494,8 @@ int scan_counts(const uint32_t *counts, uint64_t *base, size_t n, void *stream) 
     case 4: return CALL(4);                                                         \
     case 5: case 6: return CALL(6);                                                 \
     case 7: case 8: return CALL(8);                                                 \
+    case 9: case 10: case 11: case 12: return CALL(12);                             \
+    case 13: case 14: case 15: case 16: return CALL(16);                            \
     default: return (int)hipErrorInvalidValue;                                      \
     }
 
