@@ -21,7 +21,7 @@ ABI_SYMBOLS = (
     "rrx_num_states", "rrx_set_class", "rrx_ref_initial", "rrx_ref_is_final", "rrx_ref_row",
     "rrx_engine", "rrx_engine_name", "rrx_useful_states", "rrx_byte_classes", "rrx_words_per_set", "rrx_accepts_empty",
     "rrx_program_words",
-    "rrx_corpus_create", "rrx_corpus_num_lines", "rrx_corpus_num_bytes", "rrx_corpus_free", "rrx_corpus_bitmap_words",
+    "rrx_corpus_create", "rrx_corpus_create_ex", "rrx_corpus_stripe_bytes", "rrx_corpus_num_lines", "rrx_corpus_num_bytes", "rrx_corpus_free", "rrx_corpus_bitmap_words",
     "rrx_match_corpus", "rrx_bitmap_to_bytes",
     "rrx_match_extents", "rrx_match_host", "rrx_match_cstr",
 )
@@ -63,6 +63,8 @@ def _load():
         "rrx_accepts_empty": (i32, [vp]),
         "rrx_program_words": (sz, [vp, i32, vp, sz]),
         "rrx_corpus_create": (i32, [i32, vp, sz, vp, C.POINTER(vp)]),
+        "rrx_corpus_create_ex": (i32, [i32, vp, sz, u32, vp, C.POINTER(vp)]),
+        "rrx_corpus_stripe_bytes": (u32, [vp]),
         "rrx_corpus_num_lines": (sz, [vp]),
         "rrx_corpus_num_bytes": (sz, [vp]),
         "rrx_corpus_free": (None, [vp]),
@@ -136,7 +138,7 @@ class IteratorWrapper:
 class Corpus:
     """A device-resident batch of '\\n'-delimited strings plus its per-tile newline index (rrx_corpus)."""
 
-    def __init__(self, data, device=None, stream=None):
+    def __init__(self, data, device=None, stream=None, stripe=0):
         import torch
         if isinstance(data, (bytes, bytearray, memoryview)):
             data = torch.frombuffer(bytearray(data), dtype=torch.uint8) if len(data) else torch.empty(0, dtype=torch.uint8)
@@ -148,8 +150,8 @@ class Corpus:
         self.device = data.device.index
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
-            _check(_L.rrx_corpus_create(self.device, C.c_void_p(data.data_ptr() if data.numel() else 0), data.numel(),
-                                        _stream_ptr(stream), C.byref(self._h)))
+            _check(_L.rrx_corpus_create_ex(self.device, C.c_void_p(data.data_ptr() if data.numel() else 0), data.numel(),
+                                           stripe, _stream_ptr(stream), C.byref(self._h)))
 
     def __del__(self):
         if getattr(self, "_h", None) and _L is not None:      # (_L is None during interpreter shutdown)
@@ -163,6 +165,10 @@ class Corpus:
     @property
     def num_bytes(self):
         return _L.rrx_corpus_num_bytes(self._h)
+
+    @property
+    def stripe(self):
+        return _L.rrx_corpus_stripe_bytes(self._h)
 
 
 class RRegex:

@@ -132,6 +132,7 @@ struct rrx_corpus {
     int device = 0;
     const uint8_t *d_bytes = nullptr;
     size_t nbytes = 0, nstripes = 0, nlines = 0;
+    uint32_t stripe = 0;            // bytes per lane for this corpus
     uint32_t *d_counts = nullptr;   // [nstripes] newlines per stripe, then one flags word
     uint64_t *d_base = nullptr;     // [nstripes+1] exclusive prefix
     bool has_high = false;          // some byte >= 0x80 occurs
@@ -217,7 +218,13 @@ size_t rrx_program_words(const rrx_regex *re, int kind, uint32_t *out, size_t ca
 }
 
 int rrx_corpus_create(int device, const void *d_bytes, size_t nbytes, void *stream, rrx_corpus **out) {
+    return rrx_corpus_create_ex(device, d_bytes, nbytes, 0, stream, out);
+}
+
+int rrx_corpus_create_ex(int device, const void *d_bytes, size_t nbytes, uint32_t stripe_bytes, void *stream, rrx_corpus **out) {
     if (!out || (nbytes && !d_bytes)) return fail(RRX_ERR_ARG, "null argument");
+    if (stripe_bytes && (stripe_bytes < dev::kMinStripe || stripe_bytes > dev::kMaxStripe || (stripe_bytes & (stripe_bytes - 1))))
+        return fail(RRX_ERR_ARG, "stripe must be a power of two in [1024, 16384]");
     if (reinterpret_cast<uintptr_t>(d_bytes) & 15) return fail(RRX_ERR_ARG, "corpus base must be 16-byte aligned");
     *out = nullptr;
     HIP_TRY(hipSetDevice(device));
@@ -225,14 +232,15 @@ int rrx_corpus_create(int device, const void *d_bytes, size_t nbytes, void *stre
     c->device = device;
     c->d_bytes = static_cast<const uint8_t *>(d_bytes);
     c->nbytes = nbytes;
-    c->nstripes = (nbytes + dev::kStripe - 1) / dev::kStripe;
+    c->stripe = stripe_bytes ? stripe_bytes : dev::pick_stripe(nbytes);
+    c->nstripes = (nbytes + c->stripe - 1) / c->stripe;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->d_counts), (c->nstripes + 1) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_base), (c->nstripes + 1) * sizeof(uint64_t));
     if (e != hipSuccess) { rrx_corpus_free(c); return hip_fail(e, "hipMalloc(line index)"); }
     uint32_t *d_flags = c->d_counts + c->nstripes;
     e = hipMemsetAsync(d_flags, 0, sizeof(uint32_t), (hipStream_t)stream);
     if (e != hipSuccess) { rrx_corpus_free(c); return hip_fail(e, "hipMemsetAsync(flags)"); }
-    int rc = dev::count_newlines_per_stripe(c->d_bytes, nbytes, c->d_counts, c->nstripes, d_flags, stream);
+    int rc = dev::count_newlines_per_stripe(c->d_bytes, nbytes, c->stripe, c->d_counts, c->nstripes, d_flags, stream);
     if (!rc) rc = dev::scan_counts(c->d_counts, c->d_base, c->nstripes, stream);
     if (rc) { rrx_corpus_free(c); return hip_fail((hipError_t)rc, "line index launch"); }
     uint64_t total = 0;
@@ -250,6 +258,7 @@ int rrx_corpus_create(int device, const void *d_bytes, size_t nbytes, void *stre
 }
 size_t rrx_corpus_num_lines(const rrx_corpus *c) { return c->nlines; }
 size_t rrx_corpus_num_bytes(const rrx_corpus *c) { return c->nbytes; }
+uint32_t rrx_corpus_stripe_bytes(const rrx_corpus *c) { return c->stripe; }
 void rrx_corpus_free(rrx_corpus *c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
@@ -270,8 +279,8 @@ int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accep
     // the kernel merges words with atomic OR: start from an all-zero bitmap
     HIP_TRY(hipMemsetAsync(d_accept_bits, 0, rrx_corpus_bitmap_words(c) * sizeof(uint32_t), (hipStream_t)stream));
     int e = re->engine == RRX_ENGINE_NFA
-                ? dev::match_stripes_nfa(t->nfa, c->d_bytes, c->nbytes, c->d_base, c->nstripes, d_accept_bits, stream)
-                : dev::match_stripes_dfa(t->line, c->has_high, c->d_bytes, c->nbytes, c->d_base, c->nstripes, d_accept_bits, stream);
+                ? dev::match_stripes_nfa(t->nfa, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream)
+                : dev::match_stripes_dfa(t->line, c->has_high, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream);
     if (e) return hip_fail((hipError_t)e, "match_stripes launch");
     return RRX_OK;
 }

@@ -7,13 +7,22 @@ namespace rrx {
 namespace dev {
 
 // Geometry of the batch kernel: lane g of the grid owns the lines that START in the contiguous stripe
-// bytes [g*kStripe, (g+1)*kStripe) and follows its last line past the stripe end.  Every lane streams its
+// bytes [g*stripe, (g+1)*stripe) and follows its last line past the stripe end.  Every lane streams its
 // stripe straight from HBM into registers, kRound bytes (8 x 16 B) per round.
 #ifndef RRX_THREADS
 #define RRX_THREADS 1024
 #endif
 constexpr int kThreads = RRX_THREADS;       // lanes per workgroup: one LDS copy of the tables serves them all
-constexpr int kStripe = 4096;
+// Stripe = bytes per lane: a per-corpus power of two in [kMinStripe, kMaxStripe], chosen so that a corpus
+// yields about half a million lanes (big stripes amortise the per-stripe work: following the straddling line,
+// the final flush; small ones keep every CU busy on a small corpus).
+constexpr uint32_t kMinStripe = 1024, kMaxStripe = 16384;
+constexpr size_t kTargetLanes = (size_t)1 << 19;
+inline uint32_t pick_stripe(size_t nbytes) {
+    uint32_t s = kMinStripe;
+    while (s < kMaxStripe && nbytes / s > kTargetLanes) s *= 2;
+    return s;
+}
 constexpr int kRound = 128;                      // one whole cache line per lane per round
 constexpr int kMaxNfaWords = 16;                 // 512 positions per lane-resident state set
 constexpr uint32_t kWideColumns = 129;           // columns 0..127 = byte values, 128 = any byte >= 0x80
@@ -51,15 +60,15 @@ struct LineDfaDevice {
 };
 
 // All launchers are asynchronous on `stream` and return a hipError_t value (0 = success).
-int count_newlines_per_stripe(const uint8_t *bytes, size_t nbytes, uint32_t *counts, size_t nstripes, uint32_t *flags, void *stream);
+int count_newlines_per_stripe(const uint8_t *bytes, size_t nbytes, uint32_t stripe, uint32_t *counts, size_t nstripes, uint32_t *flags, void *stream);
 int scan_counts(const uint32_t *counts, uint64_t *base, size_t n, void *stream);
 int expand_bits(const uint32_t *bits, size_t nlines, uint8_t *out, void *stream);
 
 // accept_bits: bitmap, bit i = line i accepted; must be zeroed before the launch (the launchers do not)
-int match_stripes_nfa(const NfaDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *stripe_base,
+int match_stripes_nfa(const NfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
                       size_t nstripes, uint32_t *accept_bits, void *stream);
-int match_stripes_dfa(const LineDfaDevice &p, bool clamp_high, const uint8_t *bytes, size_t nbytes, const uint64_t *stripe_base,
-                      size_t nstripes, uint32_t *accept_bits, void *stream);
+int match_stripes_dfa(const LineDfaDevice &p, bool clamp_high, const uint8_t *bytes, size_t nbytes, uint32_t stripe,
+                      const uint64_t *stripe_base, size_t nstripes, uint32_t *accept_bits, void *stream);
 
 // items i = bytes[off[i] .. off[i+1] - trim) ; trim = 1 drops a trailing delimiter byte per item
 int match_extents_nfa(const NfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim,

@@ -7,7 +7,7 @@
 // Pure integer/bitwise work, HBM-read bound by design: no MFMA.
 //
 // Batch kernel (match_stripes<Engine>) — the text never touches LDS:
-//   * lane g of the grid owns the lines that START in its contiguous 4 KiB stripe of the corpus and follows
+//   * lane g of the grid owns the lines that START in its contiguous stripe (1-16 KiB) of the corpus and follows
 //     its last line past the stripe end, so every line is stepped by exactly one lane from its first byte;
 //   * each lane streams its own stripe from HBM straight into registers, one whole 128-byte line
 //     (8 x global_load_dwordx4) per round through a rotating 8-slot register buffer: slot i is refilled for
@@ -18,7 +18,7 @@
 //     output word and merged into the accept BITMAP (bit i = line i) with one global atomic OR per filled
 //     word (about one per 32 lines; per-line byte stores cost 23x their size in HBM write traffic);
 //     line index = stripe_base[g] + newlines seen so far, stripe_base being the per-stripe newline prefix
-//     the corpus carries (8 bytes per 4 KiB of text): no per-line offset array is ever read.
+//     the corpus carries (8 bytes per stripe of text): no per-line offset array is ever read.
 #include <hip/hip_runtime.h>
 
 #include "device.hpp"
@@ -46,31 +46,73 @@ struct LineDfaEngine {
     struct State { uint32_t e; };
     const uint8_t *tab;                    // LDS, byte-addressed
     const uint8_t *cls;                    // LDS [256] (classed form)
-    uint32_t start_off;
+    uint32_t start_off, dead_off;
 
     static size_t lds_bytes(const LineDfaDevice &p) { return (size_t)p.nrows * p.stride * 4 + (WIDE ? 0 : 256); }
+    typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
     __device__ void load(const LineDfaDevice &p, uint8_t *lds) {
         uint32_t *t = reinterpret_cast<uint32_t *>(lds);
         const int n = (int)(p.nrows * p.stride);
-        for (int i = threadIdx.x; i < n; i += blockDim.x) t[i] = p.table[i];
+        // In the SDWA form the low half of an entry is the ABSOLUTE LDS address of the next row, so that
+        // e.word[0] + 4*c is the address to read, with no base to add per byte.
+        const uint32_t base = (WIDE && !CLAMP) ? (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds : 0u;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) t[i] = p.table[i] + base;
         if (!WIDE) {
             uint8_t *c = lds + (size_t)n * 4;
             for (int i = threadIdx.x; i < 256; i += blockDim.x) c[i] = p.cls[i];
             cls = c;
         }
         tab = lds;
-        start_off = p.start_off;
+        start_off = p.start_off + base;
+        dead_off = base;
     }
     __device__ __forceinline__ State fresh() const { return State{start_off}; }
-    __device__ __forceinline__ State skipping() const { return State{0}; }          // dead row: waits for '\n'
+    __device__ __forceinline__ State skipping() const { return State{dead_off}; }   // dead row: waits for '\n'
+    // Byte K of text word w, fused with the result accumulation bits = (bits << nl) | acc.  A wave64 integer
+    // VALU op costs 4 cycles on a CDNA4 SIMD, so the step is written as 4 VALU + 1 LDS per byte with the
+    // field extractions folded into SDWA operand selects (hipcc emits 6-7 for the plain C form below):
+    //     c4   = w.byte[K] << 2                 v_lshlrev_b32_sdwa   src1_sel:BYTE_K
+    //     addr = e.word[0] + c4                 v_add_u32_sdwa       src0_sel:WORD_0
+    //     e    = LDS[addr]                      ds_read_b32
+    //     bits = bits << e.byte[2]              v_lshlrev_b32_sdwa   src0_sel:BYTE_2
+    //     bits = bits |  e.byte[3]              v_or_b32_sdwa        src0_sel:BYTE_3
+    template <int K>
+    __device__ __forceinline__ void consume(State &st, uint32_t w, uint32_t &bits) const {
+        if constexpr (WIDE && !CLAMP) {
+            uint32_t c4, addr;
+            const uint32_t two = 2;
+            if constexpr (K == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(c4) : "v"(two), "v"(w));
+            if constexpr (K == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(c4) : "v"(two), "v"(w));
+            if constexpr (K == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(c4) : "v"(two), "v"(w));
+            if constexpr (K == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(c4) : "v"(two), "v"(w));
+            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(addr) : "v"(st.e), "v"(c4));
+#ifdef RRX_PROBE_NO_LOOKUP      /* measurement only: no table read (results are wrong) */
+            st.e = addr & 0x1ffffu;
+#else
+            st.e = *reinterpret_cast<lds_u32_ptr>(addr);
+#endif
+            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(bits) : "v"(st.e), "v"(bits));
+            asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(bits) : "v"(st.e), "v"(bits));
+        } else {
+            uint32_t nl, acc;
+            step(st, (w >> (8 * K)) & 0xffu, nl, acc);
+            bits = (bits << nl) | acc;
+        }
+    }
     __device__ __forceinline__ void step(State &st, uint32_t c, uint32_t &nl, uint32_t &acc) const {
         uint32_t col;
         if (WIDE) col = CLAMP ? (c < 128u ? c : 128u) : c;      // !CLAMP: the corpus holds no byte >= 0x80
         else col = cls[c];
-        const uint32_t off = (st.e & 0xffffu) + (col << 2);
-        st.e = *reinterpret_cast<const uint32_t *>(tab + off);
+#ifdef RRX_PROBE_NO_LOOKUP      /* measurement only: same feed and result path, no table read (results are wrong) */
+        st.e = st.e * 33u + col;
+        nl = col == 10u ? 1u : 0u;
+        acc = st.e & nl;
+#else
+        const uint32_t off = (st.e & 0xffffu) + (col << 2);              // (absolute LDS address in the SDWA form)
+        st.e = (WIDE && !CLAMP) ? *reinterpret_cast<lds_u32_ptr>(off) : *reinterpret_cast<const uint32_t *>(tab + off);
         nl = (st.e >> 16) & 0xffu;
         acc = st.e >> 24;
+#endif
     }
 };
 
@@ -141,6 +183,12 @@ struct LineNfaEngine : NfaCore<W> {
 #pragma unroll
         for (int i = 0; i < W; i++) st.s[i] = 0;
         return st;
+    }
+    template <int K>
+    __device__ __forceinline__ void consume(State &st, uint32_t w, uint32_t &bits) const {
+        uint32_t nl, acc;
+        step(st, (w >> (8 * K)) & 0xffu, nl, acc);
+        bits = (bits << nl) | acc;
     }
     __device__ __forceinline__ void step(State &st, uint32_t c, uint32_t &nl, uint32_t &acc) const {
         const bool isnl = c == '\n';
@@ -243,7 +291,7 @@ struct Results {
 
 template <class Engine, class Program>
 __global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, const uint8_t *__restrict__ bytes, size_t nbytes,
-                                                                  const uint64_t *__restrict__ stripe_base,
+                                                                  uint32_t stripe, const uint64_t *__restrict__ stripe_base,
                                                                   uint32_t *__restrict__ accept_bits) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     Engine eng;
@@ -251,9 +299,9 @@ __global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, c
     __syncthreads();
 
     const size_t g = (size_t)blockIdx.x * kThreads + threadIdx.x;
-    const size_t start = g * (size_t)kStripe;
+    const size_t start = g * (size_t)stripe;
     if (start >= nbytes) return;
-    const size_t stripe_end = start + kStripe;
+    const size_t stripe_end = start + stripe;
     const size_t my_end = stripe_end < nbytes ? stripe_end : nbytes;
     const bool fresh = start == 0 || bytes[start - 1] == '\n';
     typename Engine::State st = fresh ? eng.fresh() : eng.skipping();
@@ -266,6 +314,10 @@ __global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, c
     //   2  split burst: 4 loads at the start of the round, the other 4 one unit later
     //   3  single buffer: the burst for the next line is issued after the current one has been consumed
     //      (no register double buffer: other waves of the SIMD cover the fetch)
+    //   5  as 3, but the burst is issued as two half-line bursts: 4 loads, wait for them, then the other 4
+    //      (which then hit the line the first four just brought into L1)
+    //   4  as 3, plus a one-dword touch of the line after next at the start of every round, so that the burst
+    //      finds its line already in L2
     size_t pos = start;
     const uint4 *src = reinterpret_cast<const uint4 *>(bytes + start);
     constexpr int kSlots = kRound / 16;
@@ -275,11 +327,25 @@ __global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, c
     uint4 nxt[kSlots];
 #endif
     if (rounds > 0) {
+#if RRX_FEED == 5
+#pragma unroll
+        for (int i = 0; i < kSlots / 2; i++) buf[i] = src[i];
+        asm volatile("" ::"v"(buf[0].x), "v"(buf[1].x), "v"(buf[2].x), "v"(buf[3].x));
+#pragma unroll
+        for (int i = kSlots / 2; i < kSlots; i++) buf[i] = src[i];
+#else
 #pragma unroll
         for (int i = 0; i < kSlots; i++) buf[i] = src[i];
+#endif
     }
     for (int r = 0; r < rounds; r++) {
         const bool more = r + 1 < rounds;
+#if RRX_FEED == 4
+        if (more) {
+            uint32_t touch = reinterpret_cast<const uint32_t *>(src + (r + 1) * kSlots)[0];
+            asm volatile("" ::"v"(touch));                   // keep the load, discard the value
+        }
+#endif
 #if RRX_FEED == 1
         if (more) {
 #pragma unroll
@@ -303,10 +369,11 @@ __global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, c
             }
 #endif
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                uint32_t nl, acc;
-                eng.step(st, (w[k >> 2] >> (8 * (k & 3))) & 0xffu, nl, acc);
-                res.push(nl, acc);
+            for (int q = 0; q < 4; q++) {
+                eng.template consume<0>(st, w[q], res.bits);
+                eng.template consume<1>(st, w[q], res.bits);
+                eng.template consume<2>(st, w[q], res.bits);
+                eng.template consume<3>(st, w[q], res.bits);
             }
             if (res.bits >> 15) res.flush();                 // <= 16 more results fit before the next check
         }
@@ -314,10 +381,19 @@ __global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, c
 #if RRX_FEED == 1 || RRX_FEED == 2
 #pragma unroll
         for (int i = 0; i < kSlots; i++) buf[i] = nxt[i];
-#elif RRX_FEED == 3
+#elif RRX_FEED == 3 || RRX_FEED == 4
         if (more) {
 #pragma unroll
             for (int i = 0; i < kSlots; i++) buf[i] = src[(r + 1) * kSlots + i];
+        }
+#elif RRX_FEED == 5
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < kSlots / 2; i++) buf[i] = src[(r + 1) * kSlots + i];
+            // consume the first half's registers so that the compiler waits for them here
+            asm volatile("" ::"v"(buf[0].x), "v"(buf[1].x), "v"(buf[2].x), "v"(buf[3].x));
+#pragma unroll
+            for (int i = kSlots / 2; i < kSlots; i++) buf[i] = src[(r + 1) * kSlots + i];
         }
 #endif
     }
@@ -337,6 +413,15 @@ __global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, c
     const bool started = fresh || res.seen > 0;
     if (started && bytes[my_end - 1] != '\n') {
         uint32_t nl = 0, acc = 0;
+        // 16 bytes per load (pos is 16-byte aligned here unless the corpus ended inside my stripe)
+        while (pos + 16 <= nbytes && !nl) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(bytes + pos);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 16; k++)
+                if (!nl) eng.step(st, (w[k >> 2] >> (8 * (k & 3))) & 0xffu, nl, acc);
+            pos += 16;
+        }
         for (; pos < nbytes && !nl; pos++) eng.step(st, bytes[pos], nl, acc);
         if (!nl) eng.step(st, '\n', nl, acc);       // the corpus ends without '\n': end of data ends the line
         res.push(nl, acc);
@@ -372,13 +457,13 @@ __global__ __launch_bounds__(kThreads) void match_extents_kernel(Program prog, c
 // ============================================================================================ line index
 // counts[g] = number of '\n' in stripe g, streamed exactly like the match kernel streams it.  Also raises
 // *flags bit 0 if any byte >= 0x80 occurs (the match kernel then clamps such bytes to the dead column).
-__global__ __launch_bounds__(256) void count_newlines_kernel(const uint8_t *__restrict__ bytes, size_t nbytes,
+__global__ __launch_bounds__(256) void count_newlines_kernel(const uint8_t *__restrict__ bytes, size_t nbytes, uint32_t stripe,
                                                               uint32_t *__restrict__ counts, size_t nstripes,
                                                               uint32_t *__restrict__ flags) {
     const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (g >= nstripes) return;
-    const size_t start = g * (size_t)kStripe;
-    const size_t end = start + kStripe < nbytes ? start + kStripe : nbytes;
+    const size_t start = g * (size_t)stripe;
+    const size_t end = start + stripe < nbytes ? start + stripe : nbytes;
     const uint4 *src = reinterpret_cast<const uint4 *>(bytes + start);
     const int units = (int)((end - start) / 16);
     uint32_t cnt = 0, high = 0;
@@ -444,14 +529,14 @@ __global__ __launch_bounds__(1024) void scan_counts_kernel(const uint32_t *__res
 }
 
 template <class Engine, class Program>
-int launch_stripes(const Program &p, size_t table_bytes, const uint8_t *bytes, size_t nbytes, const uint64_t *stripe_base,
-                   size_t nstripes, uint32_t *accept, void *stream) {
+int launch_stripes(const Program &p, size_t table_bytes, const uint8_t *bytes, size_t nbytes, uint32_t stripe,
+                   const uint64_t *stripe_base, size_t nstripes, uint32_t *accept, void *stream) {
     if (!nstripes) return 0;
     auto k = match_stripes_kernel<Engine, Program>;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)table_bytes);
     if (e != hipSuccess) return (int)e;
     size_t blocks = (nstripes + kThreads - 1) / kThreads;
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), table_bytes, (hipStream_t)stream, p, bytes, nbytes, stripe_base, accept);
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), table_bytes, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept);
     return (int)hipGetLastError();
 }
 
@@ -469,10 +554,11 @@ int launch_extents(const Program &p, size_t table_bytes, const uint8_t *bytes, c
 
 }  // namespace
 
-int count_newlines_per_stripe(const uint8_t *bytes, size_t nbytes, uint32_t *counts, size_t nstripes, uint32_t *flags, void *stream) {
+int count_newlines_per_stripe(const uint8_t *bytes, size_t nbytes, uint32_t stripe, uint32_t *counts, size_t nstripes, uint32_t *flags,
+                              void *stream) {
     if (!nstripes) return 0;
     size_t blocks = (nstripes + 255) / 256;
-    hipLaunchKernelGGL(count_newlines_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, bytes, nbytes, counts, nstripes, flags);
+    hipLaunchKernelGGL(count_newlines_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, bytes, nbytes, stripe, counts, nstripes, flags);
     return (int)hipGetLastError();
 }
 int expand_bits(const uint32_t *bits, size_t nlines, uint8_t *out, void *stream) {
@@ -500,15 +586,15 @@ int scan_counts(const uint32_t *counts, uint64_t *base, size_t n, void *stream) 
     }
 
 // The device tables are padded to the instantiated width by the caller (NfaDevice::W is the padded width).
-int match_stripes_nfa(const NfaDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *stripe_base, size_t nstripes,
-                      uint32_t *accept, void *stream) {
-#define CALL(WW) launch_stripes<LineNfaEngine<WW>, NfaDevice>(p, LineNfaEngine<WW>::lds_bytes(p), bytes, nbytes, stripe_base, nstripes, accept, stream)
+int match_stripes_nfa(const NfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
+                      size_t nstripes, uint32_t *accept, void *stream) {
+#define CALL(WW) launch_stripes<LineNfaEngine<WW>, NfaDevice>(p, LineNfaEngine<WW>::lds_bytes(p), bytes, nbytes, stripe, stripe_base, nstripes, accept, stream)
     RRX_NFA_DISPATCH(CALL)
 #undef CALL
 }
-int match_stripes_dfa(const LineDfaDevice &p, bool clamp_high, const uint8_t *bytes, size_t nbytes, const uint64_t *stripe_base,
-                      size_t nstripes, uint32_t *accept, void *stream) {
-#define GO(WIDE, CLAMP) launch_stripes<LineDfaEngine<WIDE, CLAMP>, LineDfaDevice>(p, LineDfaEngine<WIDE, CLAMP>::lds_bytes(p), bytes, nbytes, stripe_base, nstripes, accept, stream)
+int match_stripes_dfa(const LineDfaDevice &p, bool clamp_high, const uint8_t *bytes, size_t nbytes, uint32_t stripe,
+                      const uint64_t *stripe_base, size_t nstripes, uint32_t *accept, void *stream) {
+#define GO(WIDE, CLAMP) launch_stripes<LineDfaEngine<WIDE, CLAMP>, LineDfaDevice>(p, LineDfaEngine<WIDE, CLAMP>::lds_bytes(p), bytes, nbytes, stripe, stripe_base, nstripes, accept, stream)
     if (p.wide) return clamp_high ? GO(true, true) : GO(true, false);
     return GO(false, false);
 #undef GO

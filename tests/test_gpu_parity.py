@@ -12,7 +12,8 @@ from pyoracle import OracleError, OracleRegex
 torch = pytest.importorskip("torch")
 pytestmark = pytest.mark.gpu
 
-STRIPE, ROUND, BLOCK = 4096, 64, 256 * 4096      # kernel geometry (device.hpp)
+ROUND, LANES = 128, 1024                         # kernel geometry (device.hpp): bytes per round, lanes per workgroup
+STRIPES = (1024, 4096, 16384)                    # bytes per lane; every corpus test runs at each of them
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -31,17 +32,20 @@ def engines_for(pattern):
     return out
 
 
-def check(pattern, data, oracle=None):
+def check(pattern, data, oracle=None, stripes=(0,)):
     data = np.frombuffer(data, dtype=np.uint8) if isinstance(data, (bytes, bytearray)) else data
     o = oracle or OracleRegex(pattern)
     want = o.match_lines(data)
-    corpus = rr.Corpus(torch.from_numpy(np.array(data, copy=True)).cuda() if len(data) else torch.empty(0, dtype=torch.uint8, device="cuda"))
-    assert corpus.num_lines == len(want)
-    for r in engines_for(pattern):
-        got = r.match_corpus(corpus).cpu().numpy()
-        assert got.shape == want.shape, (pattern[:40], r.engine_name)
-        bad = np.nonzero(got != want)[0]
-        assert bad.size == 0, (pattern[:40], r.engine_name, "first bad line", int(bad[0]), "of", len(want))
+    dev = torch.from_numpy(np.array(data, copy=True)).cuda() if len(data) else torch.empty(0, dtype=torch.uint8, device="cuda")
+    engines = engines_for(pattern)
+    for stripe in stripes:
+        corpus = rr.Corpus(dev, stripe=stripe)
+        assert corpus.num_lines == len(want)
+        for r in engines:
+            got = r.match_corpus(corpus).cpu().numpy()
+            assert got.shape == want.shape, (pattern[:40], r.engine_name)
+            bad = np.nonzero(got != want)[0]
+            assert bad.size == 0, (pattern[:40], r.engine_name, "stripe", corpus.stripe, "first bad line", int(bad[0]), "of", len(want))
     return want
 
 
@@ -107,58 +111,58 @@ def test_bytes_outside_the_domain_reject_their_line():
 
 
 def _boundary_corpus(rng, total, cut_positions, alphabet=b"ab"):
-    a = np.frombuffer(bytes(rng.choice(alphabet) for _ in range(total)), dtype=np.uint8).copy()
-    for p in cut_positions:
-        if 0 <= p < total:
-            a[p] = 10
+    a = np.frombuffer(alphabet, dtype=np.uint8)[rng.integers(0, len(alphabet), size=total)].copy()
+    cuts = np.fromiter((p for p in cut_positions if 0 <= p < total), dtype=np.int64)
+    a[cuts] = 10
     return a
 
 
-def test_lines_cut_exactly_at_round_stripe_and_block_boundaries():
-    rng = random.Random(5)
-    total = 5 * STRIPE + 777
-    for delta in (-2, -1, 0, 1):
-        cuts = [k * ROUND + delta for k in range(1, total // ROUND + 1, 3)] + [k * STRIPE + delta for k in range(1, 6)]
-        data = _boundary_corpus(rng, total, cuts)
-        check("(a|b)*abb(a|b)*", data)
-    # newlines ONLY at stripe boundaries (+delta): every lane starts mid-line or exactly on a line start
-    for delta in (-1, 0, 1):
-        data = _boundary_corpus(rng, 9 * STRIPE + 5, [k * STRIPE + delta for k in range(1, 10)])
-        check("(a|b)*abb(a|b)*", data)
+def test_lines_cut_exactly_at_round_stripe_and_workgroup_boundaries():
+    rng = np.random.default_rng(5)
+    for stripe in STRIPES:
+        total = 5 * stripe + 777
+        for delta in (-2, -1, 0, 1):
+            cuts = [k * ROUND + delta for k in range(1, total // ROUND + 1, 3)] + [k * stripe + delta for k in range(1, 6)]
+            check("(a|b)*abb(a|b)*", _boundary_corpus(rng, total, cuts), stripes=(stripe,))
+        # newlines ONLY at stripe boundaries (+delta): every lane starts mid-line or exactly on a line start
+        for delta in (-1, 0, 1):
+            data = _boundary_corpus(rng, 9 * stripe + 5, [k * stripe + delta for k in range(1, 10)])
+            check("(a|b)*abb(a|b)*", data, stripes=(stripe,))
+        # sizes that leave a partial round / partial stripe at the end
+        for n in (1, 15, 16, 127, 128, 129, stripe - 1, stripe + 1, stripe + 127, 3 * stripe + 128 + 17):
+            check("(a|b)*abb(a|b)*", _boundary_corpus(rng, n, range(7, n, 41)), stripes=(stripe,))
     # corpus sizes that are exact multiples of the stripe / of a whole workgroup, with and without trailing newline
-    for n in (STRIPE, 2 * STRIPE, BLOCK, BLOCK + STRIPE):
+    stripe = 1024
+    for n in (stripe, 2 * stripe, LANES * stripe, LANES * stripe + stripe):
         data = _boundary_corpus(rng, n, range(50, n, 97))
-        check("(a|b)*abb(a|b)*", data)
+        check("(a|b)*abb(a|b)*", data, stripes=(stripe,))
         data[-1] = 10
-        check("(a|b)*abb(a|b)*", data)
-    # sizes that leave a partial round / partial stripe at the end
-    for n in (1, 15, 16, 63, 64, 65, STRIPE - 1, STRIPE + 1, STRIPE + 63, 3 * STRIPE + 64 + 17):
-        data = _boundary_corpus(rng, n, range(7, n, 41))
-        check("(a|b)*abb(a|b)*", data)
+        check("(a|b)*abb(a|b)*", data, stripes=(stripe,))
 
 
 def test_long_lines_across_many_stripes():
-    rng = random.Random(6)
-    parts = []
-    for n in (ROUND - 1, ROUND, ROUND + 1, 5 * ROUND, STRIPE - 1, STRIPE, STRIPE + 1, STRIPE + ROUND + 5, 3 * STRIPE + 300,
-              17, 2 * STRIPE, 40 * STRIPE + 3, 5):
-        body = bytes(rng.choice(b"ab") for _ in range(n))
-        parts.append(body)
-    data = b"\n".join(parts) + b"\n"
-    check("(a|b)*abb(a|b)*", np.frombuffer(data, dtype=np.uint8))
-    check("(a|b)*", np.frombuffer(data, dtype=np.uint8))
+    rng = np.random.default_rng(6)
+    for stripe in STRIPES:
+        parts = []
+        for n in (ROUND - 1, ROUND, ROUND + 1, 5 * ROUND, stripe - 1, stripe, stripe + 1, stripe + ROUND + 5, 3 * stripe + 300,
+                  17, 2 * stripe, 40 * stripe + 3, 5):
+            parts.append(np.frombuffer(b"ab", dtype=np.uint8)[rng.integers(0, 2, size=n)])
+            parts.append(np.array([10], dtype=np.uint8))
+        data = np.concatenate(parts)
+        check("(a|b)*abb(a|b)*", data, stripes=(stripe,))
+        check("(a|b)*", data, stripes=(stripe,))
     # one single unterminated string much longer than a stripe (BASELINE config 1 shape)
-    one = np.frombuffer(bytes(rng.choice(b"abc") for _ in range(7 * STRIPE + 123)), dtype=np.uint8)
-    check("(a|b|c)*abc", one)
+    one = np.frombuffer(b"abc", dtype=np.uint8)[rng.integers(0, 3, size=7 * 4096 + 123)]
+    check("(a|b|c)*abc", one, stripes=STRIPES)
 
 
 def test_many_short_lines_overflow_the_result_register():
     # > 16 line ends inside one 16-byte unit / > 32 inside one round: exercises the early flush
-    check("a*", b"\n" * (3 * STRIPE + 5))
-    check("a?", (b"a\n" * 40000) + b"\n\n\na")
-    rng = random.Random(8)
-    data = bytes(rng.choice(b"a\n\n") for _ in range(6 * STRIPE + 11))
-    check("a{1,3}", np.frombuffer(data, dtype=np.uint8))
+    check("a*", b"\n" * (3 * 4096 + 5), stripes=STRIPES)
+    check("a?", (b"a\n" * 40000) + b"\n\n\na", stripes=STRIPES)
+    rng = np.random.default_rng(8)
+    data = np.frombuffer(b"a\n\n", dtype=np.uint8)[rng.integers(0, 3, size=6 * 4096 + 11)]
+    check("a{1,3}", data, stripes=STRIPES)
 
 
 def test_ragged_random_lines_small_alphabet():
@@ -196,7 +200,7 @@ def test_config_corpora_small():
              ("kwlines", K1000, 64 << 10), ("kwlog", K1000_CONTAINS, 128 << 10), ("c1", "abc", 1 << 20)]
     for kind, pattern, nbytes in cases:
         data = synth.corpus(kind, 11, nbytes)
-        want = check(pattern, data)
+        want = check(pattern, data, stripes=(0, 4096) if nbytes > (1 << 20) else STRIPES)
         if kind in ("email", "url"):
             assert 0.4 < want.mean() < 0.6
 
