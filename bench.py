@@ -29,9 +29,12 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8.0 TB/s spec
 HBM_ACHIEVABLE_GBS = 6290.0  # same guide: 6.29 TB/s measured float4 copy
 
 WORKLOADS = {
-    # name: (synth kind, pattern key, default bytes per GPU)
-    "url": ("url", "U2", 8 << 30),
-    "email": ("email", "EMAIL", 1 << 30),
+    # name: (synth kind, pattern key, default bytes per GPU, BASELINE config it stands for)
+    "url": ("url", "U2", 8 << 30, "configs[2]: URL regex U2"),
+    "email": ("email", "EMAIL", 1 << 30, "configs[1]: email regex"),
+    "arepeat": ("arepeat", "A300", 1 << 30, "configs[3]: a{1,300} (4 GiB over 4 GPUs = 1 GiB per GPU)"),
+    "kwlines": ("kwlines", "K1000", 8 << 30, "configs[4](i): k1|...|k1000 over lines k<n> (64 GiB over 8 GPUs = 8 GiB per GPU)"),
+    "kwlog": ("kwlog", "K1000C", 8 << 30, "configs[4](ii): .*(k1|...|k1000).* over log lines (8 GiB per GPU)"),
 }
 
 
@@ -39,7 +42,8 @@ def patterns():
     with open(os.path.join(ROOT, "tests", "golden", "kat.json")) as f:
         kat = json.load(f)
     u2 = [k["pattern"] for k in kat["kat"] if k["pattern"].startswith("(http|https|ftp)")][0]
-    return {"U2": u2, "EMAIL": r"[A-Za-z0-9._]+@[A-Za-z0-9.]+"}
+    k1000 = kat["big_states"][-1]["pattern"]
+    return {"U2": u2, "EMAIL": r"[A-Za-z0-9._]+@[A-Za-z0-9.]+", "A300": "a{1,300}", "K1000": k1000, "K1000C": ".*(" + k1000 + ").*"}
 
 
 def measured_traffic(workload, nbytes):
@@ -113,6 +117,7 @@ def main():
     ap.add_argument("--bytes", type=int, default=0, help="bytes per GPU (default: the BASELINE size)")
     ap.add_argument("--engine", default="auto", choices=["auto", "nfa", "dfa"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--pcie", action="store_true", help="also time the host-buffer entry (upload + index + match + download)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,7 +138,7 @@ def main():
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    kind, pkey, default_bytes = WORKLOADS[args.workload]
+    kind, pkey, default_bytes, config_name = WORKLOADS[args.workload]
     nbytes = args.bytes or default_bytes
     pattern = patterns()[pkey]
     engine = {"auto": rr.ENGINE_AUTO, "nfa": rr.ENGINE_NFA, "dfa": rr.ENGINE_DFA}[args.engine]
@@ -197,9 +202,8 @@ def main():
             "vs_baseline": None,
             "dtype": "u32" if regex.engine == rr.ENGINE_NFA else "u16",
             "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: URL regex U2 (%d reference states, BitSet<%d> class) over %.2f GiB synthetic URL log lines per GPU"
-                                   % (regex.states_n, regex.set_class, nbytes / 2**30) if args.workload == "url" else
-                                   "BASELINE configs[1]: email regex (%d reference states) over %.2f GiB synthetic lines per GPU" % (regex.states_n, nbytes / 2**30),
+            "config": {"workload": "BASELINE %s (%d reference states, %s class) over %.2f GiB synthetic lines per GPU"
+                                   % (config_name, regex.states_n, "BitSet<%d>" % regex.set_class if regex.set_class else "Roaring", nbytes / 2**30),
                        "pattern_states": regex.states_n, "useful_states": regex.useful_states, "engine": regex.engine_name,
                        "bytes_per_gpu": nbytes, "lines_per_gpu": nlines, "accepted_rank0": accepted, "sharding": "by lines, no collective"},
             "per_gpu_GBs": round(nbytes * args.steps / elapsed / 1e9, 2),
@@ -209,6 +213,12 @@ def main():
                          "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "algorithmic_bytes_per_launch": nbytes},
             "setup": {"generate_s": round(gen_s, 2), "index_ms": round(index_ms, 3)},
         }
+        if args.pcie:
+            sample = host[:min(nbytes, 1 << 30)]
+            regex.match_host(sample[:1 << 20])
+            t0 = time.perf_counter()
+            regex.match_host(sample)
+            res["pcie_inclusive_GBs"] = round(len(sample) / (time.perf_counter() - t0) / 1e9, 3)
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(pattern, host)
         print(json.dumps(res), flush=True)

@@ -235,13 +235,13 @@ int rrx_corpus_create_ex(int device, const void *d_bytes, size_t nbytes, uint32_
     c->stripe = stripe_bytes ? stripe_bytes : dev::pick_stripe(nbytes);
     c->nstripes = (nbytes + c->stripe - 1) / c->stripe;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->d_counts), (c->nstripes + 1) * sizeof(uint32_t));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_base), (c->nstripes + 1) * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_base), (c->nstripes + 1 + dev::scan_scratch_words(c->nstripes)) * sizeof(uint64_t));
     if (e != hipSuccess) { rrx_corpus_free(c); return hip_fail(e, "hipMalloc(line index)"); }
     uint32_t *d_flags = c->d_counts + c->nstripes;
     e = hipMemsetAsync(d_flags, 0, sizeof(uint32_t), (hipStream_t)stream);
     if (e != hipSuccess) { rrx_corpus_free(c); return hip_fail(e, "hipMemsetAsync(flags)"); }
     int rc = dev::count_newlines_per_stripe(c->d_bytes, nbytes, c->stripe, c->d_counts, c->nstripes, d_flags, stream);
-    if (!rc) rc = dev::scan_counts(c->d_counts, c->d_base, c->nstripes, stream);
+    if (!rc) rc = dev::scan_counts(c->d_counts, c->d_base, c->d_base + c->nstripes + 1, c->nstripes, stream);
     if (rc) { rrx_corpus_free(c); return hip_fail((hipError_t)rc, "line index launch"); }
     uint64_t total = 0;
     uint32_t flags = 0;

@@ -61,7 +61,8 @@ struct LineDfaDevice {
 
 // All launchers are asynchronous on `stream` and return a hipError_t value (0 = success).
 int count_newlines_per_stripe(const uint8_t *bytes, size_t nbytes, uint32_t stripe, uint32_t *counts, size_t nstripes, uint32_t *flags, void *stream);
-int scan_counts(const uint32_t *counts, uint64_t *base, size_t n, void *stream);
+int scan_counts(const uint32_t *counts, uint64_t *base, uint64_t *chunk_sums, size_t n, void *stream);   // base[n] = total
+size_t scan_scratch_words(size_t n);                                                                       // u64 words of chunk_sums
 int expand_bits(const uint32_t *bits, size_t nlines, uint8_t *out, void *stream);
 
 // accept_bits: bitmap, bit i = line i accepted; must be zeroed before the launch (the launchers do not)
