@@ -132,11 +132,19 @@ def main():
     import synth
 
     assert torch.cuda.is_available(), "bench.py needs a MI355X"
+    # RRX_BENCH_REHEARSAL=1: all ranks share GPU 0 and talk over gloo — a dry run of the N > 1 control flow on a
+    # one-GPU box (numbers from it mean nothing).  Normal runs: one rank per GPU, RCCL.
+    rehearsal = os.environ.get("RRX_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     kind, pkey, default_bytes, config_name = WORKLOADS[args.workload]
     nbytes = args.bytes or default_bytes
@@ -181,7 +189,7 @@ def main():
     elapsed = time.perf_counter() - t0
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
