@@ -248,3 +248,47 @@ def test_full_size_email_config_properties():
         want = o.match_lines(piece)                 # every chunk ends with '\n' by construction
         first = 0 if j == 0 else int(nl_before[j - 1])
         assert (acc[first:first + len(want)] == want).all(), j
+
+
+def test_corpus_golden_vectors_on_the_gpu():
+    """The committed golden accept vectors (tests/golden/corpus_golden.json, generated by the oracle) through the
+    HIP path, both engines, without running the oracle here."""
+    import json
+    import os
+    import synth
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "corpus_golden.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        data = synth.corpus(c["kind"], c["seed"], c["bytes"], chunk=c["chunk"], threads=2)
+        assert "%016x" % synth.fnv1a(data) == c["corpus_fnv1a"]
+        corpus = rr.Corpus(torch.from_numpy(data).cuda())
+        assert corpus.num_lines == c["lines"]
+        for r in engines_for(c["pattern"]):
+            acc = r.match_corpus(corpus).cpu().numpy()
+            assert (int(acc.sum()), "%016x" % synth.fnv1a(acc)) == (c["accepted"], c["accept_fnv1a"]), (c["name"], r.engine_name)
+
+
+def test_full_size_url_config_properties():
+    """BASELINE config 3 (the headline) at its full 8 GiB: engines agree bit for bit on the bitmap; sampled 1 MiB
+    chunks (each ends with a newline by construction) reproduce the ORACLE's vector at their line offsets."""
+    import synth
+    n = 8 << 30
+    host = synth.corpus("url", 2, n)
+    dev = torch.empty(n, dtype=torch.uint8, device="cuda")
+    step = 1 << 30
+    for off in range(0, n, step):
+        dev[off:off + step].copy_(torch.from_numpy(host[off:off + step]))
+    corpus = rr.Corpus(dev)
+    dfa_bits = rr.RRegex(U2, rr.ENGINE_DFA).match_corpus_bits(corpus)
+    nfa_bits = rr.RRegex(U2, rr.ENGINE_NFA).match_corpus_bits(corpus)
+    assert torch.equal(dfa_bits, nfa_bits)
+    acc = rr.RRegex(U2).match_corpus(corpus)
+    assert 0.45 < float(acc.float().mean()) < 0.55
+    chunk = 1 << 20
+    o = OracleRegex(U2)
+    for j in (0, 1, 4095, 8191):
+        piece = host[j * chunk:(j + 1) * chunk]
+        first = int((torch.from_numpy(host[:j * chunk]) == 10).sum()) if j else 0
+        want = o.match_lines(piece)
+        got = acc[first:first + len(want)].cpu().numpy()
+        assert (got == want).all(), j

@@ -129,3 +129,58 @@ def test_match_lines_splitting():
     assert list(r.match_lines(b"aa\nb\n\naaa")) == [1, 0, 1, 1]
     assert list(r.match_lines(b"aa\nb\n\naaa\n")) == [1, 0, 1, 1]
     assert list(r.match_lines(np.frombuffer(b"b", dtype=np.uint8))) == [0]
+
+
+def test_corpus_golden_vectors_reproduce():
+    """tests/golden/corpus_golden.json: the generator is frozen (corpus checksum) and the oracle's accept vectors
+    over the BASELINE-config corpora reproduce."""
+    import json
+    import os
+    import synth
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "corpus_golden.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        data = synth.corpus(c["kind"], c["seed"], c["bytes"], chunk=c["chunk"], threads=2)
+        assert "%016x" % synth.fnv1a(data) == c["corpus_fnv1a"], c["name"]
+        if c["bytes"] > (1 << 20):
+            continue                                    # the big ones are re-run by the GPU suite
+        acc = OracleRegex(c["pattern"]).match_lines(data)
+        assert (len(acc), int(acc.sum()), "%016x" % synth.fnv1a(acc)) == (c["lines"], c["accepted"], c["accept_fnv1a"]), c["name"]
+
+
+def test_oracle_is_clean_under_asan_and_ubsan(tmp_path):
+    """Sanitizers run on the CPU build only: compile the oracle with -fsanitize=address,undefined and compile a
+    batch of patterns (incl. the 7786-state keyword set and every error path) + match a few strings."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    drv = tmp_path / "drv.c"
+    drv.write_text(r'''
+#include "rr_oracle.h"
+#include <stdio.h>
+#include <string.h>
+int main(void) {
+    char line[70000], err[200];
+    while (fgets(line, sizeof line, stdin)) {
+        line[strcspn(line, "\n")] = 0;
+        rro_nfa *n = rro_compile(line, err, sizeof err);
+        if (!n) { printf("E\n"); continue; }
+        const char *t[] = {"", "a", "abc", "aaaa", "k17", "http://a.bc", "x@y.z"};
+        int m = 0;
+        for (unsigned i = 0; i < sizeof t / sizeof *t; i++) m += rro_accepts(n, (const uint8_t *)t[i], strlen(t[i]));
+        printf("%u %d\n", rro_states_n(n), m);
+        rro_free(n);
+    }
+    return 0;
+}''')
+    exe = tmp_path / "drv"
+    subprocess.check_call(["gcc", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", os.path.join(root, "oracle"),
+                           "-o", str(exe), str(drv), os.path.join(root, "oracle", "rr_oracle.c")])
+    import json
+    with open(os.path.join(root, "tests", "golden", "kat.json")) as f:
+        kat = json.load(f)
+    pats = [k["pattern"] for k in kat["kat"] if "\n" not in k["pattern"]] + [k["pattern"] for k in kat["big_states"]]
+    pats += ["a)", "|a", "a|", "()", "*a", "[", "a{2", "(|a)", "a(|b)", "[0-9][b-d](0+c*1[^a]|[0-9]{1,}([a-c]{1,6})?|k*[^a][0-9]*)?[b-d]?"]
+    p = subprocess.run([str(exe)], input=("\n".join(pats) + "\n").encode("latin-1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    assert len(p.stdout.decode().strip().split("\n")) == len(pats)
