@@ -27,7 +27,8 @@ typedef struct rrx_corpus rrx_corpus;  /* a device-resident batch of '\n'-delimi
 enum { RRX_OK = 0, RRX_ERR_PATTERN = 1, RRX_ERR_ARG = 2, RRX_ERR_HIP = 3, RRX_ERR_UNSUPPORTED = 4 };
 
 /* engine selection for rrx_compile_ex */
-enum { RRX_ENGINE_AUTO = 0, RRX_ENGINE_NFA = 1, RRX_ENGINE_DFA = 2 };
+enum { RRX_ENGINE_AUTO = 0, RRX_ENGINE_NFA = 1, RRX_ENGINE_DFA = 2, RRX_ENGINE_DFA_GLOBAL = 3 /* table kept in HBM/L2 */,
+       RRX_ENGINE_NFA_WAVE = 4 /* state set spread over the 64 lanes of a wave: up to 4096 positions */ };
 
 /* ---- compile: RRegex::RRegex(const char*), Parser.cpp:161-170 (host only, no device needed) ---------- */
 int rrx_compile(const char *pattern, rrx_regex **out);

@@ -32,6 +32,7 @@ struct DeviceTables {
     dev::NfaDevice nfa;
     dev::DfaDevice dfa;          // plain form (extents kernel)
     dev::LineDfaDevice line;     // line-mode form (batch kernel)
+    dev::WaveNfaDevice wave;     // wave-cooperative NFA
 };
 
 int instantiated_width(uint32_t W) { return W <= 4 ? (int)W : W <= 6 ? 6 : W <= 8 ? 8 : W <= 12 ? 12 : 16; }
@@ -44,9 +45,12 @@ struct rrx_regex {
     Trimmed trimmed;
     bool has_nfa = false, has_dfa = false;
     NfaProgram nfa;
+    NfaProgram nfa_wave;         // up to 4096 positions, no carry groups (wave-cooperative engine)
+    bool has_wave = false;
     DfaProgram dfa;
     int engine = 0;
     bool line_wide = false;      // DFA engine: byte-indexed rows (<= kWideMaxStates states) or class-indexed rows
+    bool line_global = false;    // DFA engine: class-indexed table too large for LDS, kept in global memory
     mutable std::mutex mu;
     mutable std::map<int, DeviceTables> on_device;
 
@@ -64,18 +68,31 @@ struct rrx_regex {
         std::vector<uint8_t> host;
         auto put = [&](const void *p, size_t n) { size_t off = (host.size() + 15) & ~(size_t)15; host.resize(off + n); std::memcpy(host.data() + off, p, n); return off; };
         size_t oB = 0, oX = 0, oC = 0, oN = 0, oA = 0, oT = 0, oL = 0;
-        if (engine == RRX_ENGINE_NFA) {
+        size_t oM = 0;
+        if (engine == RRX_ENGINE_NFA_WAVE) {
+            const uint32_t W = nfa_wave.W, WP = dev::kWaveWords;
+            std::vector<uint32_t> M((size_t)5 * WP, 0), B((size_t)256 * WP, 0), X((size_t)nfa_wave.nbits * WP, 0);
+            const std::vector<uint32_t> *src[5] = {&nfa_wave.init, &nfa_wave.fin, &nfa_wave.chain, &nfa_wave.self, &nfa_wave.excm};
+            for (int k = 0; k < 5; k++) for (uint32_t w = 0; w < W; w++) M[(size_t)k * WP + w] = (*src[k])[w];
+            for (uint32_t c = 0; c < 256; c++) for (uint32_t w = 0; w < W; w++) B[(size_t)c * WP + w] = nfa_wave.B[(size_t)c * W + w];
+            for (uint32_t b = 0; b < nfa_wave.nbits; b++) for (uint32_t w = 0; w < W; w++) X[(size_t)b * WP + w] = nfa_wave.X[(size_t)b * W + w];
+            oM = put(M.data(), M.size() * 4);
+            oB = put(B.data(), B.size() * 4);
+            oX = put(X.data(), X.size() * 4);
+            t.wave.nbits = nfa_wave.nbits; t.wave.any_exc = nfa_wave.n_exc ? 1 : 0;
+        } else if (engine == RRX_ENGINE_NFA) {
             const uint32_t W = nfa.W, WP = (uint32_t)instantiated_width(W);
             std::vector<uint32_t> B((size_t)256 * WP, 0), X((size_t)nfa.nbits * WP, 0);
             for (uint32_t c = 0; c < 256; c++) for (uint32_t w = 0; w < W; w++) B[(size_t)c * WP + w] = nfa.B[(size_t)c * W + w];
             for (uint32_t b = 0; b < nfa.nbits; b++) for (uint32_t w = 0; w < W; w++) X[(size_t)b * WP + w] = nfa.X[(size_t)b * W + w];
             oB = put(B.data(), B.size() * 4);
             oX = put(X.data(), X.size() * 4);
-            t.nfa.W = WP; t.nfa.nbits = nfa.nbits; t.nfa.any_exc = nfa.n_exc ? 1 : 0;
+            t.nfa.W = WP; t.nfa.nbits = nfa.nbits; t.nfa.any_exc = nfa.n_exc ? 1 : 0; t.nfa.any_carry = nfa.n_carry ? 1 : 0;
             std::memset(&t.nfa.masks, 0, sizeof t.nfa.masks);
             for (uint32_t w = 0; w < W; w++) {
                 t.nfa.masks.init[w] = nfa.init[w]; t.nfa.masks.fin[w] = nfa.fin[w]; t.nfa.masks.chain[w] = nfa.chain[w];
                 t.nfa.masks.self[w] = nfa.self[w]; t.nfa.masks.excm[w] = nfa.excm[w];
+                t.nfa.masks.cgrp[w] = nfa.cgrp[w]; t.nfa.masks.ctgt[w] = nfa.ctgt[w];
             }
         } else {
             oC = put(dfa.cls, 256);
@@ -92,10 +109,11 @@ struct rrx_regex {
             uint8_t lcls[256];
             for (int c = 0; c < 256; c++) lcls[c] = dfa.cls[c];
             lcls['\n'] = (uint8_t)K;                                     // own column for the line terminator
-            const uint32_t row_bytes = stride * 4;
+            const uint32_t row_bytes = line_global ? stride : stride * 4;   // global form: entry indices, not byte offsets
+            const int nl_bit = line_global ? 30 : 16, acc_bit = line_global ? 31 : 24;
             for (uint32_t d = 0; d < D; d++) {
                 uint32_t *row = &T[(size_t)d * stride];
-                const uint32_t nl_entry = dfa.start * row_bytes | 1u << 16 | (dfa.accepting[d] ? 1u << 24 : 0u);
+                const uint32_t nl_entry = dfa.start * row_bytes | 1u << nl_bit | (dfa.accepting[d] ? 1u << acc_bit : 0u);
                 if (wide) {
                     for (uint32_t c = 0; c < 128; c++) row[c] = (uint32_t)dfa.next[(size_t)d * K + dfa.cls[c]] * row_bytes;
                     row['\n'] = nl_entry;
@@ -108,11 +126,16 @@ struct rrx_regex {
             oT = put(T.data(), T.size() * 4);
             oL = put(lcls, 256);
             t.line.nrows = D; t.line.stride = stride; t.line.start_off = dfa.start * row_bytes; t.line.wide = wide ? 1 : 0;
+            t.line.in_global = line_global ? 1 : 0;
         }
         HIP_TRY(hipMalloc(&t.blob, host.size() + 16));
         HIP_TRY(hipMemcpy(t.blob, host.data(), host.size(), hipMemcpyHostToDevice));
         const uint8_t *base = static_cast<const uint8_t *>(t.blob);
-        if (engine == RRX_ENGINE_NFA) {
+        if (engine == RRX_ENGINE_NFA_WAVE) {
+            t.wave.masks = reinterpret_cast<const uint32_t *>(base + oM);
+            t.wave.B = reinterpret_cast<const uint32_t *>(base + oB);
+            t.wave.X = reinterpret_cast<const uint32_t *>(base + oX);
+        } else if (engine == RRX_ENGINE_NFA) {
             t.nfa.B = reinterpret_cast<const uint32_t *>(base + oB);
             t.nfa.X = reinterpret_cast<const uint32_t *>(base + oX);
         } else {
@@ -144,22 +167,27 @@ const char *rrx_last_error(void) { return g_err.c_str(); }
 
 int rrx_compile_ex(const char *pattern, int engine, rrx_regex **out) {
     if (!pattern || !out) return fail(RRX_ERR_ARG, "null argument");
-    if (engine < RRX_ENGINE_AUTO || engine > RRX_ENGINE_DFA) return fail(RRX_ERR_ARG, "unknown engine");
+    if (engine < RRX_ENGINE_AUTO || engine > RRX_ENGINE_NFA_WAVE) return fail(RRX_ERR_ARG, "unknown engine");
     *out = nullptr;
     rrx_regex *re = new rrx_regex();
     try {
         re->pattern = pattern;
         re->ref = build_reference_automaton(re->pattern);
         re->trimmed = trim(re->ref);
-        if (engine != RRX_ENGINE_DFA) re->has_nfa = lower_nfa(re->trimmed, dev::kMaxNfaWords * 32, re->nfa);
-        if (engine != RRX_ENGINE_NFA) {
-            re->has_dfa = lower_dfa(re->trimmed, kMaxSubsetStates, re->dfa);
+        const Reduced red = reduce(re->trimmed);
+        if (engine == RRX_ENGINE_AUTO || engine == RRX_ENGINE_NFA) re->has_nfa = lower_nfa(red, dev::kMaxNfaWords * 32, re->nfa);
+        if (engine != RRX_ENGINE_NFA && engine != RRX_ENGINE_NFA_WAVE) {
+            re->has_dfa = lower_dfa(red, kMaxSubsetStates, re->dfa);
             if (re->has_dfa) {
-                re->line_wide = re->dfa.nstates <= dev::kWideMaxStates;
+                re->line_wide = re->dfa.nstates <= dev::kWideMaxStates && engine != RRX_ENGINE_DFA_GLOBAL;
                 const size_t classed_entries = (size_t)re->dfa.nstates * (re->dfa.ncls + 2);
-                if (!re->line_wide && classed_entries > dev::kClassedMaxEntries) re->has_dfa = false;
+                re->line_global = engine == RRX_ENGINE_DFA_GLOBAL || (!re->line_wide && classed_entries > dev::kClassedMaxEntries);
+                if (re->line_global && classed_entries >= ((size_t)1 << 24)) re->has_dfa = false;
             }
         }
+        // the wave-cooperative form: when asked for, or as the last resort of AUTO
+        if (engine == RRX_ENGINE_NFA_WAVE || (engine == RRX_ENGINE_AUTO && !re->has_nfa && !re->has_dfa))
+            re->has_wave = lower_nfa(red, dev::kWaveWords * 32, re->nfa_wave, /*allow_carry=*/false);
     } catch (const PatternError &e) {
         delete re;
         return fail(RRX_ERR_PATTERN, e.what());
@@ -167,9 +195,12 @@ int rrx_compile_ex(const char *pattern, int engine, rrx_regex **out) {
         delete re;
         return fail(RRX_ERR_PATTERN, std::string("internal: ") + e.what());
     }
+    // AUTO: the LDS-resident table when it fits, else the register-resident NFA, else the table in global memory
     if (engine == RRX_ENGINE_NFA) re->engine = re->has_nfa ? RRX_ENGINE_NFA : 0;
-    else if (engine == RRX_ENGINE_DFA) re->engine = re->has_dfa ? RRX_ENGINE_DFA : 0;
-    else re->engine = re->has_dfa ? RRX_ENGINE_DFA : re->has_nfa ? RRX_ENGINE_NFA : 0;
+    else if (engine == RRX_ENGINE_DFA || engine == RRX_ENGINE_DFA_GLOBAL) re->engine = re->has_dfa ? RRX_ENGINE_DFA : 0;
+    else if (engine == RRX_ENGINE_NFA_WAVE) re->engine = re->has_wave ? RRX_ENGINE_NFA_WAVE : 0;
+    else re->engine = (re->has_dfa && !re->line_global) ? RRX_ENGINE_DFA : re->has_nfa ? RRX_ENGINE_NFA : re->has_dfa ? RRX_ENGINE_DFA
+                      : re->has_wave ? RRX_ENGINE_NFA_WAVE : 0;
     if (!re->engine) {
         char msg[200];
         std::snprintf(msg, sizeof msg, "automaton too large for the requested engine (%u useful states)", re->trimmed.n);
@@ -193,19 +224,21 @@ uint32_t rrx_ref_row(const rrx_regex *re, uint32_t state, unsigned c, uint32_t *
 }
 int rrx_engine(const rrx_regex *re) { return re->engine; }
 const char *rrx_engine_name(const rrx_regex *re) {
-    return re->engine == RRX_ENGINE_DFA ? (re->line_wide ? "dfa-wide-table" : "dfa-classed-table") : "nfa-shift-and";
+    if (re->engine == RRX_ENGINE_NFA_WAVE) return "nfa-wave-cooperative";
+    if (re->engine != RRX_ENGINE_DFA) return "nfa-shift-and";
+    return re->line_global ? "dfa-global-table" : re->line_wide ? "dfa-wide-table" : "dfa-classed-table";
 }
 uint32_t rrx_useful_states(const rrx_regex *re) { return re->trimmed.n; }
 uint32_t rrx_byte_classes(const rrx_regex *re) { return re->trimmed.ncls; }
-uint32_t rrx_words_per_set(const rrx_regex *re) { return re->has_nfa ? re->nfa.W : 0; }
-int rrx_accepts_empty(const rrx_regex *re) { return re->has_nfa ? re->nfa.accepts_empty : re->dfa.accepts_empty; }
+uint32_t rrx_words_per_set(const rrx_regex *re) { return re->has_nfa ? re->nfa.W : re->has_wave ? re->nfa_wave.W : 0; }
+int rrx_accepts_empty(const rrx_regex *re) { return re->has_nfa ? re->nfa.accepts_empty : re->has_wave ? re->nfa_wave.accepts_empty : re->dfa.accepts_empty; }
 
 size_t rrx_program_words(const rrx_regex *re, int kind, uint32_t *out, size_t cap) {
     std::vector<uint32_t> w;
-    if (kind == RRX_ENGINE_NFA && re->has_nfa) {
-        const NfaProgram &p = re->nfa;
+    if ((kind == RRX_ENGINE_NFA && re->has_nfa) || (kind == RRX_ENGINE_NFA_WAVE && re->has_wave)) {
+        const NfaProgram &p = kind == RRX_ENGINE_NFA ? re->nfa : re->nfa_wave;
         w = {p.W, p.nbits, p.n_exc, p.accepts_empty ? 1u : 0u};
-        for (auto *v : {&p.init, &p.fin, &p.chain, &p.self, &p.excm, &p.B, &p.X}) w.insert(w.end(), v->begin(), v->end());
+        for (auto *v : {&p.init, &p.fin, &p.chain, &p.self, &p.excm, &p.cgrp, &p.ctgt, &p.B, &p.X}) w.insert(w.end(), v->begin(), v->end());
     } else if (kind == RRX_ENGINE_DFA && re->has_dfa) {
         const DfaProgram &d = re->dfa;
         w = {d.nstates, d.ncls, d.start, d.accepts_empty ? 1u : 0u};
@@ -278,7 +311,9 @@ int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accep
     if (!c->nlines) return RRX_OK;
     // the kernel merges words with atomic OR: start from an all-zero bitmap
     HIP_TRY(hipMemsetAsync(d_accept_bits, 0, rrx_corpus_bitmap_words(c) * sizeof(uint32_t), (hipStream_t)stream));
-    int e = re->engine == RRX_ENGINE_NFA
+    int e = re->engine == RRX_ENGINE_NFA_WAVE
+                ? dev::match_stripes_wave_nfa(t->wave, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream)
+            : re->engine == RRX_ENGINE_NFA
                 ? dev::match_stripes_nfa(t->nfa, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream)
                 : dev::match_stripes_dfa(t->line, c->has_high, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream);
     if (e) return hip_fail((hipError_t)e, "match_stripes launch");
@@ -302,7 +337,8 @@ int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, cons
     if (rc) return rc;
     HIP_TRY(hipSetDevice(device));
     const uint8_t *b = static_cast<const uint8_t *>(d_bytes);
-    int e = re->engine == RRX_ENGINE_NFA ? dev::match_extents_nfa(t->nfa, b, d_off, nitems, trim, d_accept, stream)
+    int e = re->engine == RRX_ENGINE_NFA_WAVE ? dev::match_extents_wave_nfa(t->wave, b, d_off, nitems, trim, d_accept, stream)
+            : re->engine == RRX_ENGINE_NFA ? dev::match_extents_nfa(t->nfa, b, d_off, nitems, trim, d_accept, stream)
                                          : dev::match_extents_dfa(t->dfa, b, d_off, nitems, trim, d_accept, stream);
     if (e) return hip_fail((hipError_t)e, "match_extents launch");
     return RRX_OK;

@@ -31,13 +31,24 @@ constexpr uint32_t kClassedMaxEntries = 16384;   // row byte offsets are 16-bit:
 
 struct NfaMasks {                                // passed by value -> SGPRs
     uint32_t init[kMaxNfaWords], fin[kMaxNfaWords], chain[kMaxNfaWords], self[kMaxNfaWords], excm[kMaxNfaWords];
+    uint32_t cgrp[kMaxNfaWords], ctgt[kMaxNfaWords];   // add-carry rules: runs and their targets
 };
 
 struct NfaDevice {                               // tables in HBM (copied to LDS by every workgroup)
-    uint32_t W = 0, nbits = 0, any_exc = 0;
+    uint32_t W = 0, nbits = 0, any_exc = 0, any_carry = 0;
     NfaMasks masks;
     const uint32_t *B = nullptr;                 // [256][W]
     const uint32_t *X = nullptr;                 // [nbits][W]
+};
+
+// Wave-cooperative NFA (automata beyond kMaxNfaWords*32 positions): the state set is spread over the 64 lanes
+// of a wave, one 64-bit word per lane (4096 positions); every table row is kWaveWords 32-bit words in HBM/L2.
+constexpr uint32_t kWaveWords = 128;
+struct WaveNfaDevice {
+    uint32_t nbits = 0, any_exc = 0;
+    const uint32_t *masks = nullptr;             // [5][kWaveWords]: init, fin, chain, self, excm
+    const uint32_t *B = nullptr;                 // [256][kWaveWords]
+    const uint32_t *X = nullptr;                 // [nbits][kWaveWords]
 };
 
 // Plain DFA (extents kernel: '\n' is an ordinary byte).
@@ -55,6 +66,8 @@ struct LineDfaDevice {
     uint32_t stride = 0;                         // entries per row
     uint32_t start_off = 0;                      // byte offset of the start row
     uint32_t wide = 0;                           // 1: columns are byte values (kWideColumns); 0: byte classes
+    uint32_t in_global = 0;                      // 1: table too large for LDS, read from HBM/L2; entry = next row's
+                                                 //    first-entry index (24 bits) | nl << 30 | accept << 31
     const uint32_t *table = nullptr;             // [nrows][stride]
     const uint8_t *cls = nullptr;                // [256] (classed form only)
 };
@@ -70,6 +83,11 @@ int match_stripes_nfa(const NfaDevice &p, const uint8_t *bytes, size_t nbytes, u
                       size_t nstripes, uint32_t *accept_bits, void *stream);
 int match_stripes_dfa(const LineDfaDevice &p, bool clamp_high, const uint8_t *bytes, size_t nbytes, uint32_t stripe,
                       const uint64_t *stripe_base, size_t nstripes, uint32_t *accept_bits, void *stream);
+
+int match_stripes_wave_nfa(const WaveNfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
+                           size_t nstripes, uint32_t *accept_bits, void *stream);
+int match_extents_wave_nfa(const WaveNfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim,
+                           uint8_t *accept, void *stream);
 
 // items i = bytes[off[i] .. off[i+1] - trim) ; trim = 1 drops a trailing delimiter byte per item
 int match_extents_nfa(const NfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim,

@@ -116,6 +116,33 @@ struct LineDfaEngine {
     }
 };
 
+// ---- table DFA whose table stays in global memory (L2-resident): any automaton up to 65535 interned sets ----
+struct LineDfaGlobalEngine {
+    struct State { uint32_t e; };          // low 24 bits = index of the current row's first entry
+    const uint32_t *__restrict__ tab;      // HBM / L2
+    const uint8_t *cls;                    // LDS [256]
+    uint32_t start_off;
+
+    static size_t lds_bytes(const LineDfaDevice &) { return 256; }
+    __device__ void load(const LineDfaDevice &p, uint8_t *lds) {
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) lds[i] = p.cls[i];
+        cls = lds; tab = p.table; start_off = p.start_off;
+    }
+    __device__ __forceinline__ State fresh() const { return State{start_off}; }
+    __device__ __forceinline__ State skipping() const { return State{0}; }
+    __device__ __forceinline__ void step(State &st, uint32_t c, uint32_t &nl, uint32_t &acc) const {
+        st.e = tab[(st.e & 0xffffffu) + cls[c]];
+        nl = (st.e >> 30) & 1u;
+        acc = st.e >> 31;
+    }
+    template <int K>
+    __device__ __forceinline__ void consume(State &st, uint32_t w, uint32_t &bits) const {
+        uint32_t nl, acc;
+        step(st, (w >> (8 * K)) & 0xffu, nl, acc);
+        bits = (bits << nl) | acc;
+    }
+};
+
 // ---- shift-and NFA: state set in W registers --------------------------------------------------------
 template <int W>
 struct NfaCore {
@@ -123,7 +150,7 @@ struct NfaCore {
     const uint32_t *B;      // LDS [256][W]
     const uint32_t *X;      // LDS [nbits][W]
     NfaMasks m;
-    bool any_exc;
+    bool any_exc, any_carry;
 
     static size_t lds_bytes(const NfaDevice &p) { return ((size_t)256 * W + (size_t)p.nbits * W) * 4; }
     __device__ void load(const NfaDevice &p, uint8_t *lds) {
@@ -131,7 +158,7 @@ struct NfaCore {
         uint32_t *x = b + 256 * W;
         for (int i = threadIdx.x; i < 256 * W; i += blockDim.x) b[i] = p.B[i];
         for (int i = threadIdx.x; i < (int)p.nbits * W; i += blockDim.x) x[i] = p.X[i];
-        B = b; X = x; m = p.masks; any_exc = p.any_exc != 0;
+        B = b; X = x; m = p.masks; any_exc = p.any_exc != 0; any_carry = p.any_carry != 0;
     }
     __device__ __forceinline__ bool accepting(const State &st) const {
         uint32_t a = 0;
@@ -139,7 +166,7 @@ struct NfaCore {
         for (int i = 0; i < W; i++) a |= st.s[i] & m.fin[i];
         return a != 0;
     }
-    // next = ( ((S << 1) & CHAIN) | (S & SELF) | OR_{e in S & EXC} X[e] ) & B[c]
+    // next = ( ((S << 1) & CHAIN) | (S & SELF) | (((S & CGRP) + CGRP) & CTGT) | OR_{e in S & EXC} X[e] ) & B[c]
     __device__ __forceinline__ void advance(State &st, uint32_t c) const {
         uint32_t t[W];
         uint32_t exc = 0;
@@ -149,6 +176,15 @@ struct NfaCore {
             uint32_t sh = __builtin_amdgcn_alignbit(st.s[i], lo, 31);
             t[i] = (sh & m.chain[i]) | (st.s[i] & m.self[i]);
             exc |= st.s[i] & m.excm[i];
+        }
+        if (any_carry) {                                     // ((S & CGRP) + CGRP) & CTGT as one multiword add
+            uint32_t cy = 0;
+#pragma unroll
+            for (int i = 0; i < W; i++) {
+                const uint64_t sum = (uint64_t)(st.s[i] & m.cgrp[i]) + m.cgrp[i] + cy;
+                t[i] |= (uint32_t)sum & m.ctgt[i];
+                cy = (uint32_t)(sum >> 32);
+            }
         }
         if (any_exc && exc) {
 #pragma unroll
@@ -258,6 +294,7 @@ struct Results {
     uint32_t seen = 0;
     uint64_t word;
     bool drop_first;
+    bool writer = true;                    // wave-cooperative kernels: every lane mirrors the bookkeeping, one writes
     uint32_t *__restrict__ out;
 
     __device__ __forceinline__ void begin(uint64_t first_line, bool drop, uint32_t *bitmap) {
@@ -272,7 +309,7 @@ struct Results {
             outw |= rev << fill;
             uint32_t nf = fill + (uint32_t)n;
             if (nf >= 32u) {                                 // then fill >= 1
-                if (outw) atomicOr(&out[word], outw);
+                if (outw && writer) atomicOr(&out[word], outw);
                 word++;
                 outw = rev >> (32u - fill);
                 nf -= 32u;
@@ -284,13 +321,18 @@ struct Results {
     }
     __device__ __forceinline__ void finish() {
         flush();
-        if (outw) atomicOr(&out[word], outw);
+        if (outw && writer) atomicOr(&out[word], outw);
         outw = 0;
     }
 };
 
+#ifdef RRX_WAVES_PER_EU
+#define RRX_OCC __attribute__((amdgpu_waves_per_eu(RRX_WAVES_PER_EU, RRX_WAVES_PER_EU)))
+#else
+#define RRX_OCC
+#endif
 template <class Engine, class Program>
-__global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, const uint8_t *__restrict__ bytes, size_t nbytes,
+__global__ __launch_bounds__(kThreads) RRX_OCC void match_stripes_kernel(Program prog, const uint8_t *__restrict__ bytes, size_t nbytes,
                                                                   uint32_t stripe, const uint64_t *__restrict__ stripe_base,
                                                                   uint32_t *__restrict__ accept_bits) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -427,6 +469,138 @@ __global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, c
         res.push(nl, acc);
     }
     res.finish();
+}
+
+// ============================================================================================ wave-cooperative NFA
+// For automata too large for one lane's registers: the 64 lanes of a wave hold ONE state set, lane l the
+// positions [64 l, 64 l + 64) as two 32-bit words.  A wave walks the lines that start in its stripe one byte
+// at a time; all control flow is wave-uniform (one string per wave), so the exception loop does not diverge.
+// The shift crosses lanes with a single DPP-style lane shuffle; table rows are read coalesced (8 B per lane).
+struct WaveNfa {
+    uint32_t init[2], fin[2], chain[2], self[2], excm[2];
+    const uint2 *B, *X;
+    bool any_exc;
+    int lane;
+
+    __device__ void load(const WaveNfaDevice &p) {
+        lane = threadIdx.x & 63;
+        const uint2 *m = reinterpret_cast<const uint2 *>(p.masks);
+        uint2 v;
+        v = m[0 * 64 + lane]; init[0] = v.x; init[1] = v.y;
+        v = m[1 * 64 + lane]; fin[0] = v.x; fin[1] = v.y;
+        v = m[2 * 64 + lane]; chain[0] = v.x; chain[1] = v.y;
+        v = m[3 * 64 + lane]; self[0] = v.x; self[1] = v.y;
+        v = m[4 * 64 + lane]; excm[0] = v.x; excm[1] = v.y;
+        B = reinterpret_cast<const uint2 *>(p.B);
+        X = reinterpret_cast<const uint2 *>(p.X);
+        any_exc = p.any_exc != 0;
+    }
+    __device__ __forceinline__ bool accepting(uint32_t s0, uint32_t s1) const { return __any(((s0 & fin[0]) | (s1 & fin[1])) != 0); }
+    // c is wave-uniform
+    __device__ __forceinline__ void advance(uint32_t &s0, uint32_t &s1, uint32_t c) const {
+        const uint2 b = B[(size_t)c * 64 + lane];
+        uint32_t below = __shfl_up(s1, 1, 64);                 // word of the lane below me
+        if (lane == 0) below = 0;
+        uint32_t t0 = (((s0 << 1) | (below >> 31)) & chain[0]) | (s0 & self[0]);
+        uint32_t t1 = (((s1 << 1) | (s0 >> 31)) & chain[1]) | (s1 & self[1]);
+        if (any_exc) {
+            uint32_t e0 = s0 & excm[0], e1 = s1 & excm[1];
+            unsigned long long live = __ballot((e0 | e1) != 0);
+            while (live) {                                       // wave-uniform: one exception position per turn
+                const int src = __ffsll((long long)live) - 1;
+                const uint32_t w0 = __shfl(e0, src, 64), w1 = __shfl(e1, src, 64);
+                const int bit = w0 ? __ffs(w0) - 1 : 32 + __ffs(w1) - 1;
+                if (lane == src) { if (bit < 32) e0 &= ~(1u << bit); else e1 &= ~(1u << (bit - 32)); }
+                const uint2 row = X[(size_t)(64 * src + bit) * 64 + lane];
+                t0 |= row.x; t1 |= row.y;
+                live = __ballot((e0 | e1) != 0);
+            }
+        }
+        s0 = t0 & b.x; s1 = t1 & b.y;
+    }
+};
+
+// One wave per stripe (the stripe geometry and the result path are the lane kernel's, at wave granularity).
+// Everything below is wave-uniform; every lane mirrors the result bookkeeping, lane 0 alone writes.
+__global__ __launch_bounds__(256) void match_stripes_wave_kernel(WaveNfaDevice prog, const uint8_t *__restrict__ bytes, size_t nbytes,
+                                                                  uint32_t stripe, const uint64_t *__restrict__ stripe_base,
+                                                                  uint32_t *__restrict__ accept_bits) {
+    WaveNfa eng;
+    eng.load(prog);
+    const int lane = eng.lane;
+    const size_t g = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const size_t start = g * (size_t)stripe;
+    if (start >= nbytes) return;
+    const size_t stripe_end = start + stripe;
+    const size_t my_end = stripe_end < nbytes ? stripe_end : nbytes;
+    const bool fresh = start == 0 || bytes[start - 1] == '\n';
+    uint32_t s0 = fresh ? eng.init[0] : 0, s1 = fresh ? eng.init[1] : 0;   // not fresh: dead until the first '\n'
+    Results res;
+    res.begin(stripe_base[g], !fresh, accept_bits);
+    res.writer = lane == 0;
+
+    // ---- the lines inside my stripe, 64 bytes of text per turn (one per lane, broadcast with readlane)
+    for (size_t pos = start; pos < my_end; pos += 64) {
+        const size_t p = pos + lane;
+        const uint32_t mine = p < my_end ? bytes[p] : 0;
+        const int avail = my_end - pos < 64 ? (int)(my_end - pos) : 64;
+        for (int k = 0; k < avail; k++) {
+            const uint32_t c = __builtin_amdgcn_readlane(mine, k);
+            if (c == '\n') {
+                res.push(1, eng.accepting(s0, s1) ? 1u : 0u);
+                if (res.bits >> 30) res.flush();
+                s0 = eng.init[0]; s1 = eng.init[1];
+            } else if (c == 0 || c >= 0x80) { s0 = 0; s1 = 0; }
+            else eng.advance(s0, s1, c);
+        }
+    }
+    res.flush();
+
+    // ---- follow my last line past the stripe end (same ownership rule as the lane kernel)
+    const bool started = fresh || res.seen > 0;
+    if (started && bytes[my_end - 1] != '\n') {
+        bool ended = false;
+        for (size_t pos = my_end; pos < nbytes && !ended; pos += 64) {
+            const size_t p = pos + lane;
+            const uint32_t mine = p < nbytes ? bytes[p] : 0;
+            const int avail = nbytes - pos < 64 ? (int)(nbytes - pos) : 64;
+            for (int k = 0; k < avail && !ended; k++) {
+                const uint32_t c = __builtin_amdgcn_readlane(mine, k);
+                if (c == '\n') ended = true;
+                else if (c == 0 || c >= 0x80) { s0 = 0; s1 = 0; }
+                else eng.advance(s0, s1, c);
+            }
+        }
+        res.push(1, eng.accepting(s0, s1) ? 1u : 0u);       // '\n' or the end of the corpus ends the line
+    }
+    res.finish();
+}
+
+// One wave per explicit item ('\n' ordinary).
+__global__ __launch_bounds__(256) void match_extents_wave_kernel(WaveNfaDevice prog, const uint8_t *__restrict__ bytes,
+                                                                  const uint64_t *__restrict__ off, size_t nitems, uint32_t trim,
+                                                                  uint8_t *__restrict__ accept) {
+    WaveNfa eng;
+    eng.load(prog);
+    const int lane = eng.lane;
+    const size_t i = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= nitems) return;
+    size_t b = off[i], e = off[i + 1];
+    e = e - b >= trim ? e - trim : b;
+    uint32_t s0 = eng.init[0], s1 = eng.init[1];
+    bool dead = false;
+    for (size_t pos = b; pos < e && !dead; pos += 64) {
+        const size_t p = pos + lane;
+        const uint32_t mine = p < e ? bytes[p] : 0;
+        const int avail = e - pos < 64 ? (int)(e - pos) : 64;
+        for (int k = 0; k < avail; k++) {
+            const uint32_t c = __builtin_amdgcn_readlane(mine, k);
+            if (c == 0 || c >= 0x80) { dead = true; break; }
+            eng.advance(s0, s1, c);
+        }
+    }
+    const bool ok = !dead && eng.accepting(s0, s1);
+    if (lane == 0) accept[i] = ok ? 1 : 0;
 }
 
 // ============================================================================================ extents kernel
@@ -629,9 +803,24 @@ int match_stripes_nfa(const NfaDevice &p, const uint8_t *bytes, size_t nbytes, u
 int match_stripes_dfa(const LineDfaDevice &p, bool clamp_high, const uint8_t *bytes, size_t nbytes, uint32_t stripe,
                       const uint64_t *stripe_base, size_t nstripes, uint32_t *accept, void *stream) {
 #define GO(WIDE, CLAMP) launch_stripes<LineDfaEngine<WIDE, CLAMP>, LineDfaDevice>(p, LineDfaEngine<WIDE, CLAMP>::lds_bytes(p), bytes, nbytes, stripe, stripe_base, nstripes, accept, stream)
+    if (p.in_global) return launch_stripes<LineDfaGlobalEngine, LineDfaDevice>(p, 256, bytes, nbytes, stripe, stripe_base, nstripes, accept, stream);
     if (p.wide) return clamp_high ? GO(true, true) : GO(true, false);
     return GO(false, false);
 #undef GO
+}
+int match_stripes_wave_nfa(const WaveNfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
+                           size_t nstripes, uint32_t *accept, void *stream) {
+    if (!nstripes) return 0;
+    size_t blocks = (nstripes + 3) / 4;
+    hipLaunchKernelGGL(match_stripes_wave_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept);
+    return (int)hipGetLastError();
+}
+int match_extents_wave_nfa(const WaveNfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim, uint8_t *accept,
+                           void *stream) {
+    if (!nitems) return 0;
+    size_t blocks = (nitems + 3) / 4;
+    hipLaunchKernelGGL(match_extents_wave_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, bytes, off, nitems, trim, accept);
+    return (int)hipGetLastError();
 }
 int match_extents_nfa(const NfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim, uint8_t *accept,
                       void *stream) {

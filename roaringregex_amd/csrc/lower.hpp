@@ -7,7 +7,10 @@
 //   NfaProgram  "shift-and with exceptions": states are split by in-label so that every state is entered
 //               on one character set (B[c] = states enterable on c); the states are laid out along a
 //               maximum path cover so that most edges are "next bit" edges.  One step is
-//                   next = ( ((S << 1) & CHAIN) | (S & SELF) | OR_{e in S & EXC} X[e] ) & B[c]
+//                   next = ( ((S << 1) & CHAIN) | (S & SELF) | (((S & CGRP) + CGRP) & CTGT) | OR_{e in S & EXC} X[e] ) & B[c]
+//               The add-carry term evaluates every rule "any position of a contiguous run -> the position right
+//               above the run" at once (what bounded repeats x{m,n} lower to): the carry out of a run lands on
+//               its target bit, which is 0 in both addends.
 //               and replaces NFA.cc:86-100 (BitSet classes) and NFA.cc:77-85 (Roaring class) alike.
 //   DfaProgram  the reachable state SETS of the reference's loop interned to small integers on the host
 //               (subset construction + minimisation): one table lookup per byte.  Used when it stays small.
@@ -44,6 +47,8 @@ struct NfaProgram {
     uint32_t n_exc = 0;                     // positions with an exception row
     uint32_t max_exc_row_words = 0;
     std::vector<uint32_t> init, fin, chain, self, excm;   // W words each
+    std::vector<uint32_t> cgrp, ctgt;                     // W words each: carry groups and their targets
+    uint32_t n_carry = 0;                                 // carry groups
     std::vector<uint32_t> X;                // nbits rows of W words: extra successors of position p
     std::vector<uint32_t> B;                // 256 rows of W words: positions enterable on byte c
     bool accepts_empty = false;
@@ -59,9 +64,25 @@ struct DfaProgram {
     bool accepts_empty = false;
 };
 
+// The trimmed automaton re-expressed over "positions" (a state split by the character set it is entered on; node 0
+// = the initial state before any input), shrunk by bisimulation quotients and pruning of dominated edges.
+// Both device programs are lowered from this one graph.
+struct Reduced {
+    struct Node {
+        CharSet label;                      // characters this position is entered on (empty for node 0)
+        bool fin = false;
+        std::vector<uint32_t> follow;       // sorted unique
+    };
+    std::vector<Node> nodes;                // empty => empty language
+    uint32_t ncls = 1;
+    uint8_t cls[256];
+    std::vector<uint8_t> cls_rep;
+};
+Reduced reduce(const Trimmed &t);
+
 // Returns false if the node count exceeds max_bits.
-bool lower_nfa(const Trimmed &t, uint32_t max_bits, NfaProgram &out);
+bool lower_nfa(const Reduced &r, uint32_t max_bits, NfaProgram &out, bool allow_carry = true);
 // Returns false if subset construction exceeds max_states.
-bool lower_dfa(const Trimmed &t, uint32_t max_states, DfaProgram &out);
+bool lower_dfa(const Reduced &r, uint32_t max_states, DfaProgram &out);
 
 }  // namespace rrx

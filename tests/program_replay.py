@@ -15,8 +15,8 @@ class NfaReplay:
             for i, x in enumerate(ws):
                 v |= x << (32 * i)
             return v
-        self.init, self.fin, self.chain, self.self_, self.excm = [big(w[o + i * W:o + (i + 1) * W]) for i in range(5)]
-        o += 5 * W
+        self.init, self.fin, self.chain, self.self_, self.excm, self.cgrp, self.ctgt = [big(w[o + i * W:o + (i + 1) * W]) for i in range(7)]
+        o += 7 * W
         self.B = [big(w[o + c * W:o + (c + 1) * W]) for c in range(256)]
         o += 256 * W
         self.X = [big(w[o + b * W:o + (b + 1) * W]) for b in range(self.nbits)]
@@ -28,6 +28,7 @@ class NfaReplay:
             if c == 0 or c >= 0x80:
                 return False
             t = ((S << 1) & self.mask & self.chain) | (S & self.self_)
+            t |= ((S & self.cgrp) + self.cgrp) & self.ctgt
             e = S & self.excm
             while e:
                 b = (e & -e).bit_length() - 1

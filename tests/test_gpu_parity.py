@@ -21,9 +21,12 @@ def _need_gpu():
     assert torch.cuda.is_available(), "GPU tests need a MI355X"
 
 
-def engines_for(pattern):
+def engines_for(pattern, small=False):
+    """One compiled regex per device engine that admits the automaton.  The wave-cooperative NFA runs one string
+    per wave (tens of MB/s), so it only joins on small inputs."""
     out = []
-    for e in (rr.ENGINE_NFA, rr.ENGINE_DFA):
+    kinds = [rr.ENGINE_NFA, rr.ENGINE_DFA, rr.ENGINE_DFA_GLOBAL] + ([rr.ENGINE_NFA_WAVE] if small else [])
+    for e in kinds:
         try:
             out.append(rr.RRegex(pattern, e))
         except rr.RRegexError as err:
@@ -37,7 +40,7 @@ def check(pattern, data, oracle=None, stripes=(0,)):
     o = oracle or OracleRegex(pattern)
     want = o.match_lines(data)
     dev = torch.from_numpy(np.array(data, copy=True)).cuda() if len(data) else torch.empty(0, dtype=torch.uint8, device="cuda")
-    engines = engines_for(pattern)
+    engines = engines_for(pattern, small=len(data) <= (1 << 18))
     for stripe in stripes:
         corpus = rr.Corpus(dev, stripe=stripe)
         assert corpus.num_lines == len(want)
@@ -62,7 +65,7 @@ def test_kat_batch():
 def test_kat_iterator_facade():
     # regex.h:113-122,150-165: it = r.get_acceptance_iter(text); it++; *it
     for k in KAT["kat"][:30] + KAT["kat"][-4:]:
-        for r in engines_for(k["pattern"]):
+        for r in engines_for(k["pattern"], small=True):
             for t, want in [(t, True) for t in k["accepts"]] + [(t, False) for t in k["rejects"]]:
                 it = r.get_acceptance_iter(t)
                 it.advance()
@@ -292,3 +295,28 @@ def test_full_size_url_config_properties():
         want = o.match_lines(piece)
         got = acc[first:first + len(want)].cpu().numpy()
         assert (got == want).all(), j
+
+
+def test_wave_cooperative_engine_on_large_automata():
+    """Automata beyond 512 positions whose subset construction explodes (AUTO -> nfa-wave-cooperative), against the
+    oracle: batch kernel at several stripe sizes, and the single-string entry."""
+    rng = random.Random(77)
+    p = "(a|b)*a(a|b){600}"
+    r = rr.RRegex(p)
+    assert r.engine_name == "nfa-wave-cooperative"
+    o = OracleRegex(p)
+    lines = []
+    for n in (0, 1, 600, 601, 602, 603, 700, 1300, 5000):
+        for _ in range(3):
+            lines.append("".join(rng.choice("ab") for _ in range(n)))
+        lines.append("a" * n)
+        lines.append("b" * n)
+    data = ("\n".join(lines)).encode()
+    want = o.match_lines(np.frombuffer(data, dtype=np.uint8))
+    assert 0 < want.sum() < len(want)
+    dev = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+    for stripe in STRIPES:
+        got = r.match_corpus(rr.Corpus(dev, stripe=stripe)).cpu().numpy()
+        assert (got == want).all(), stripe
+    for t in lines[:12]:
+        assert (r.get_acceptance_iter(t).advance().value() is not None) == o.accepts(t)

@@ -145,3 +145,27 @@ def test_reduction_statistics():
     assert w[1] == 86 and w[2] == 0           # a pure shift chain: no exception rows
     r = rr.RRegex(K1000)
     assert r.states_n == 7786 and r.engine == rr.ENGINE_DFA
+
+
+def test_wave_program_for_automata_beyond_one_lane():
+    """> 512 positions and an exploding subset construction: AUTO falls through to the wave-cooperative NFA
+    (the Roaring class).  Its program (no carry groups) replays to the oracle's answers."""
+    rng = random.Random(41)
+    for p, alphabet, lens in [("(a|b)*a(a|b){600}", "ab", (598, 601, 602, 640)), ("a{1,900}", "a", (1, 899, 900, 901, 950)),
+                              ("(ab|cd){2,300}e", "abcde", (5, 401, 601, 603))]:
+        o = OracleRegex(p)
+        r = rr.RRegex(p)
+        if p.startswith("(a|b)"):
+            assert r.engine == rr.ENGINE_NFA_WAVE and r.engine_name == "nfa-wave-cooperative"
+        w = rr.RRegex(p, rr.ENGINE_NFA_WAVE).program(rr.ENGINE_NFA_WAVE)
+        assert w is not None and w[1] > 512
+        rep = NfaReplay(w)
+        texts = ["", alphabet[0]]
+        for n in lens:
+            texts.append("".join(rng.choice(alphabet) for _ in range(n)))
+            texts.append(alphabet[0] * n)
+            texts.append(("ab" * n)[:n] if "b" in alphabet else alphabet[0] * n)
+        if p.startswith("(ab|cd)"):
+            texts += ["ab" * 150 + "e", "abcd" * 150 + "e", "ab" * 301 + "e", "ab" + "e", "abab" + "e"]
+        for t in texts:
+            assert rep.accepts(t.encode()) == o.accepts(t), (p, len(t))
