@@ -79,20 +79,29 @@ struct LineDfaEngine {
     template <int K>
     __device__ __forceinline__ void consume(State &st, uint32_t w, uint32_t &bits) const {
         if constexpr (WIDE && !CLAMP) {
-            uint32_t c4, addr;
-            const uint32_t two = 2;
-            if constexpr (K == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(c4) : "v"(two), "v"(w));
-            if constexpr (K == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(c4) : "v"(two), "v"(w));
-            if constexpr (K == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(c4) : "v"(two), "v"(w));
-            if constexpr (K == 3) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(c4) : "v"(two), "v"(w));
-            asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(addr) : "v"(st.e), "v"(c4));
 #ifdef RRX_PROBE_NO_LOOKUP      /* measurement only: no table read (results are wrong) */
-            st.e = addr & 0x1ffffu;
+            st.e = (st.e + ((w >> (8 * K)) & 0xffu) * 4u) & 0x1ffffu;
+            bits = (bits << ((st.e >> 16) & 1u)) | (st.e >> 24);
 #else
-            st.e = *reinterpret_cast<lds_u32_ptr>(addr);
+            // One asm block per byte (separate statements made hipcc pad every byte with an s_nop).  The block
+            // waits for its own LDS read; the only other memory traffic of the wave are global loads (vmcnt).
+            uint32_t t0, t1;
+#define RRX_STEP(SEL)                                                                                                        \
+            asm volatile("v_lshlrev_b32_sdwa %[c4], %[two], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL "\n\t" \
+                         "v_add_u32_sdwa %[ad], %[e], %[c4] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"       \
+                         "ds_read_b32 %[e], %[ad]\n\t"                                                                                  \
+                         "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
+                         "v_lshlrev_b32_sdwa %[b], %[e], %[b] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n\t"     \
+                         "v_or_b32_sdwa %[b], %[e], %[b] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD"              \
+                         : [e] "+v"(st.e), [b] "+v"(bits), [c4] "=&v"(t0), [ad] "=&v"(t1)                                               \
+                         : [w] "v"(w), [two] "v"(2u)                                                                                    \
+                         : "memory")
+            if constexpr (K == 0) RRX_STEP("BYTE_0");
+            if constexpr (K == 1) RRX_STEP("BYTE_1");
+            if constexpr (K == 2) RRX_STEP("BYTE_2");
+            if constexpr (K == 3) RRX_STEP("BYTE_3");
+#undef RRX_STEP
 #endif
-            asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(bits) : "v"(st.e), "v"(bits));
-            asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(bits) : "v"(st.e), "v"(bits));
         } else {
             uint32_t nl, acc;
             step(st, (w >> (8 * K)) & 0xffu, nl, acc);
