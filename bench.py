@@ -222,7 +222,7 @@ def main():
             "setup": {"generate_s": round(gen_s, 2), "index_ms": round(index_ms, 3)},
         }
         if args.pcie:
-            sample = host[:min(nbytes, 1 << 30)]
+            sample = host[:min(nbytes, 4 << 30)]
             regex.match_host(sample[:1 << 20])
             t0 = time.perf_counter()
             regex.match_host(sample)

@@ -236,8 +236,8 @@ class RRegex:
         """Host bytes in, numpy accept vector out (upload + index + match + download; synchronous)."""
         import numpy as np
         a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
-        cap = int((a == 10).sum()) + 1
-        out = np.zeros(cap, dtype=np.uint8)
+        cap = len(a) + 1                       # a buffer of n bytes holds at most n + 1 strings; untouched pages are free
+        out = np.empty(cap, dtype=np.uint8)
         n = C.c_size_t(0)
         _check(_L.rrx_match_host(self._h, self.device, C.c_void_p(a.ctypes.data if len(a) else 0), len(a),
                                  C.c_void_p(out.ctypes.data), cap, C.byref(n)))

@@ -344,35 +344,93 @@ int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, cons
     return RRX_OK;
 }
 
+// Host buffer in, one byte per string out.  Large inputs are pipelined: the caller's buffer is pinned in place
+// (hipHostRegister), cut into line-aligned chunks, and the H2D copy of chunk i+1 runs on one stream while index +
+// match + download of chunk i run on the other (two device buffers).  PCIe inclusive; never the benchmarked rate.
+static int match_host_chunk(const rrx_regex *re, int device, uint8_t *d_text, size_t len, hipStream_t st, uint32_t *d_bits,
+                            uint8_t *d_acc, uint8_t *accept, size_t cap, size_t line_off, size_t *nlines_out) {
+    rrx_corpus *c = nullptr;
+    int rc = rrx_corpus_create(device, d_text, len, st, &c);             // waits for the chunk's copy and index
+    if (rc) return rc;
+    const size_t n = c->nlines;
+    rc = rrx_match_corpus(re, c, d_bits, st);
+    if (!rc) rc = rrx_bitmap_to_bytes(device, d_bits, n, d_acc, st);
+    if (!rc && line_off < cap) {
+        const size_t take = n < cap - line_off ? n : cap - line_off;
+        hipError_t e = hipMemcpyAsync(accept + line_off, d_acc, take, hipMemcpyDeviceToHost, st);
+        if (e != hipSuccess) rc = hip_fail(e, "accept readback");
+    }
+    hipError_t e = hipStreamSynchronize(st);                             // the index arrays of `c` are freed next
+    if (!rc && e != hipSuccess) rc = hip_fail(e, "chunk sync");
+    rrx_corpus_free(c);
+    *nlines_out = n;
+    return rc;
+}
+
 int rrx_match_host(const rrx_regex *re, int device, const void *bytes, size_t nbytes, uint8_t *accept, size_t cap, size_t *nlines) {
     if (!re || (nbytes && !bytes) || !nlines) return fail(RRX_ERR_ARG, "null argument");
     HIP_TRY(hipSetDevice(device));
-    void *d_bytes = nullptr;
-    uint8_t *d_acc = nullptr;
-    rrx_corpus *c = nullptr;
+    *nlines = 0;
+    if (!nbytes) return RRX_OK;
+    const uint8_t *host = static_cast<const uint8_t *>(bytes);
+    const size_t kChunk = (size_t)256 << 20;
+    const size_t buf_bytes = (nbytes < kChunk ? nbytes : kChunk) + 64;
+    const size_t max_lines = buf_bytes;                                   // a chunk of n bytes holds at most n lines
+    uint8_t *d_text[2] = {nullptr, nullptr}, *d_acc[2] = {nullptr, nullptr};
+    uint32_t *d_bits[2] = {nullptr, nullptr};
+    hipStream_t st[2] = {nullptr, nullptr};
+    const int nbuf = nbytes > kChunk ? 2 : 1;
     int rc = RRX_OK;
-    hipError_t e = hipMalloc(&d_bytes, nbytes + 16);
-    if (e == hipSuccess && nbytes) e = hipMemcpy(d_bytes, bytes, nbytes, hipMemcpyHostToDevice);
-    if (e != hipSuccess) rc = hip_fail(e, "corpus upload");
-    if (!rc) rc = rrx_corpus_create(device, d_bytes, nbytes, nullptr, &c);
-    uint32_t *d_bits = nullptr;
-    if (!rc) {
-        *nlines = c->nlines;
-        e = hipMalloc(reinterpret_cast<void **>(&d_acc), c->nlines + 64);
-        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_bits), (rrx_corpus_bitmap_words(c) + 4) * sizeof(uint32_t));
-        if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(accept)");
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < nbuf && e == hipSuccess; i++) {
+        e = hipMalloc(reinterpret_cast<void **>(&d_text[i]), buf_bytes);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_acc[i]), max_lines + 64);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&d_bits[i]), (max_lines / 32 + 4) * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipStreamCreate(&st[i]);
     }
-    if (!rc) rc = rrx_match_corpus(re, c, d_bits, nullptr);
-    if (!rc) rc = rrx_bitmap_to_bytes(device, d_bits, c->nlines, d_acc, nullptr);
-    if (!rc) {
-        size_t n = c->nlines < cap ? c->nlines : cap;
-        e = hipMemcpy(accept, d_acc, n, hipMemcpyDeviceToHost);    // synchronises with the default stream
-        if (e != hipSuccess) rc = hip_fail(e, "accept readback");
+    if (e != hipSuccess) rc = hip_fail(e, "pipeline buffers");
+    // pin the caller's pages so that the copies are asynchronous DMA (best effort)
+    const bool pinned = !rc && nbuf == 2 && hipHostRegister(const_cast<uint8_t *>(host), nbytes, hipHostRegisterDefault) == hipSuccess;
+    if (!pinned) (void)hipGetLastError();
+
+    // chunk boundaries: right after the last '\n' of each window (a window without any '\n' is taken whole: the
+    // line continues, and since a line must be matched by one launch such inputs fall back to one big chunk)
+    std::vector<size_t> cuts{0};
+    while (!rc && cuts.back() < nbytes) {
+        size_t lo = cuts.back(), hi = lo + kChunk < nbytes ? lo + kChunk : nbytes;
+        if (hi < nbytes) {
+            size_t q = hi;
+            while (q > lo && host[q - 1] != '\n') q--;
+            if (q == lo) { rc = fail(RRX_ERR_UNSUPPORTED, "a single line longer than 256 MiB: use rrx_corpus_create on a device buffer"); break; }
+            hi = q;
+        }
+        cuts.push_back(hi);
     }
-    if (d_bits) (void)hipFree(d_bits);
-    if (c) rrx_corpus_free(c);
-    if (d_acc) (void)hipFree(d_acc);
-    if (d_bytes) (void)hipFree(d_bytes);
+    const size_t nchunks = cuts.size() - 1;
+    size_t line_off = 0;
+    if (!rc) {
+        e = hipMemcpyAsync(d_text[0], host, cuts[1] - cuts[0], hipMemcpyHostToDevice, st[0]);
+        if (e != hipSuccess) rc = hip_fail(e, "chunk upload");
+    }
+    for (size_t i = 0; i < nchunks && !rc; i++) {
+        const int cur = (int)(i & 1) % nbuf, nxt = (int)((i + 1) & 1) % nbuf;
+        if (i + 1 < nchunks) {                                             // next chunk's copy overlaps this chunk's work
+            e = hipMemcpyAsync(d_text[nxt], host + cuts[i + 1], cuts[i + 2] - cuts[i + 1], hipMemcpyHostToDevice, st[nxt]);
+            if (e != hipSuccess) { rc = hip_fail(e, "chunk upload"); break; }
+        }
+        size_t n = 0;
+        rc = match_host_chunk(re, device, d_text[cur], cuts[i + 1] - cuts[i], st[cur], d_bits[cur], d_acc[cur], accept, cap, line_off, &n);
+        line_off += n;
+    }
+    for (int i = 0; i < nbuf; i++) if (st[i]) (void)hipStreamSynchronize(st[i]);
+    if (pinned) (void)hipHostUnregister(const_cast<uint8_t *>(host));
+    for (int i = 0; i < 2; i++) {
+        if (d_text[i]) (void)hipFree(d_text[i]);
+        if (d_acc[i]) (void)hipFree(d_acc[i]);
+        if (d_bits[i]) (void)hipFree(d_bits[i]);
+        if (st[i]) (void)hipStreamDestroy(st[i]);
+    }
+    *nlines = line_off;
     return rc;
 }
 

@@ -320,3 +320,18 @@ def test_wave_cooperative_engine_on_large_automata():
         assert (got == want).all(), stripe
     for t in lines[:12]:
         assert (r.get_acceptance_iter(t).advance().value() is not None) == o.accepts(t)
+
+
+def test_match_host_pipeline_equals_resident_path():
+    """rrx_match_host on an input larger than its 256 MiB chunk: pinned, chunked, double-buffered upload must give
+    exactly the accept vector of the device-resident path (and of the oracle on a sampled chunk)."""
+    import synth
+    n = (600 << 20) + 12345
+    host = synth.corpus("url", 9, n)
+    r = rr.RRegex(U2)
+    got = r.match_host(host)
+    want = r.match_corpus(rr.Corpus(torch.from_numpy(host).cuda())).cpu().numpy()
+    assert got.shape == want.shape and (got == want).all()
+    o = OracleRegex(U2)
+    piece = host[:1 << 20]
+    assert (got[:int((piece == 10).sum())] == o.match_lines(piece)).all()
