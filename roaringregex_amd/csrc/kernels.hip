@@ -23,9 +23,6 @@
 
 #include "device.hpp"
 
-#ifndef RRX_FEED
-#define RRX_FEED 3
-#endif
 
 namespace rrx {
 namespace dev {
@@ -56,7 +53,9 @@ struct LineDfaEngine {
         // In the SDWA form the low half of an entry is the ABSOLUTE LDS address of the next row, so that
         // e.word[0] + 4*c is the address to read, with no base to add per byte.
         const uint32_t base = (WIDE && !CLAMP) ? (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds : 0u;
+#ifndef RRX_PROBE_NO_TABLE      /* measurement only */
         for (int i = threadIdx.x; i < n; i += blockDim.x) t[i] = p.table[i] + base;
+#endif
         if (!WIDE) {
             uint8_t *c = lds + (size_t)n * 4;
             for (int i = threadIdx.x; i < 256; i += blockDim.x) c[i] = p.cls[i];
@@ -311,6 +310,9 @@ struct Results {
     }
     __device__ __forceinline__ void push(uint32_t nl, uint32_t acc) { bits = (bits << nl) | acc; }
     __device__ __forceinline__ void flush() {
+#ifdef RRX_PROBE_NO_FLUSH       /* measurement only */
+        seen += bits & 1u; bits = 1; return;
+#endif
         const int n = 31 - __clz((int)bits);
         if (n > 0) {                                         // n <= 31: callers flush before bits can overflow
             uint32_t rev = __brev(bits & ((1u << n) - 1u)) >> (32 - n);      // oldest line at bit 0
@@ -335,13 +337,8 @@ struct Results {
     }
 };
 
-#ifdef RRX_WAVES_PER_EU
-#define RRX_OCC __attribute__((amdgpu_waves_per_eu(RRX_WAVES_PER_EU, RRX_WAVES_PER_EU)))
-#else
-#define RRX_OCC
-#endif
 template <class Engine, class Program>
-__global__ __launch_bounds__(kThreads) RRX_OCC void match_stripes_kernel(Program prog, const uint8_t *__restrict__ bytes, size_t nbytes,
+__global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, const uint8_t *__restrict__ bytes, size_t nbytes,
                                                                   uint32_t stripe, const uint64_t *__restrict__ stripe_base,
                                                                   uint32_t *__restrict__ accept_bits) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -359,66 +356,23 @@ __global__ __launch_bounds__(kThreads) RRX_OCC void match_stripes_kernel(Program
     Results res;
     res.begin(stripe_base[g], !fresh, accept_bits);
 
-    // ---- main phase: whole 128-byte rounds of my stripe.  RRX_FEED selects how the next line is requested:
-    //   0  rotating: slot i is refilled right after it has been consumed (8 separate requests per line)
-    //   1  burst: all 8 loads of the next line are issued together at the start of the round
-    //   2  split burst: 4 loads at the start of the round, the other 4 one unit later
-    //   3  single buffer: the burst for the next line is issued after the current one has been consumed
-    //      (no register double buffer: other waves of the SIMD cover the fetch)
-    //   5  as 3, but the burst is issued as two half-line bursts: 4 loads, wait for them, then the other 4
-    //      (which then hit the line the first four just brought into L1)
-    //   4  as 3, plus a one-dword touch of the line after next at the start of every round, so that the burst
-    //      finds its line already in L2
+    // ---- main phase: whole 128-byte rounds of my stripe.  The 8 loads of a line are issued as ONE burst after the
+    // previous line has been consumed (they merge on one L2 request; other waves of the SIMD cover the fetch).
+    // Measured alternatives, all slower: refilling each 16-byte slot right after use (one L2 request per slot),
+    // a register double buffer (94 VGPRs), two half-line bursts, a software-prefetch touch.
     size_t pos = start;
     const uint4 *src = reinterpret_cast<const uint4 *>(bytes + start);
     constexpr int kSlots = kRound / 16;
     const int rounds = (int)((my_end - start) / kRound);
     uint4 buf[kSlots];
-#if RRX_FEED == 1 || RRX_FEED == 2
-    uint4 nxt[kSlots];
-#endif
     if (rounds > 0) {
-#if RRX_FEED == 5
-#pragma unroll
-        for (int i = 0; i < kSlots / 2; i++) buf[i] = src[i];
-        asm volatile("" ::"v"(buf[0].x), "v"(buf[1].x), "v"(buf[2].x), "v"(buf[3].x));
-#pragma unroll
-        for (int i = kSlots / 2; i < kSlots; i++) buf[i] = src[i];
-#else
 #pragma unroll
         for (int i = 0; i < kSlots; i++) buf[i] = src[i];
-#endif
     }
     for (int r = 0; r < rounds; r++) {
-        const bool more = r + 1 < rounds;
-#if RRX_FEED == 4
-        if (more) {
-            uint32_t touch = reinterpret_cast<const uint32_t *>(src + (r + 1) * kSlots)[0];
-            asm volatile("" ::"v"(touch));                   // keep the load, discard the value
-        }
-#endif
-#if RRX_FEED == 1
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < kSlots; i++) nxt[i] = src[(r + 1) * kSlots + i];
-        }
-#elif RRX_FEED == 2
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < kSlots / 2; i++) nxt[i] = src[(r + 1) * kSlots + i];
-        }
-#endif
 #pragma unroll
         for (int i = 0; i < kSlots; i++) {
             const uint32_t w[4] = {buf[i].x, buf[i].y, buf[i].z, buf[i].w};
-#if RRX_FEED == 0
-            if (more) buf[i] = src[(r + 1) * kSlots + i];
-#elif RRX_FEED == 2
-            if (i == 1 && more) {
-#pragma unroll
-                for (int j = kSlots / 2; j < kSlots; j++) nxt[j] = src[(r + 1) * kSlots + j];
-            }
-#endif
 #pragma unroll
             for (int q = 0; q < 4; q++) {
                 eng.template consume<0>(st, w[q], res.bits);
@@ -428,25 +382,14 @@ __global__ __launch_bounds__(kThreads) RRX_OCC void match_stripes_kernel(Program
             }
             if (res.bits >> 15) res.flush();                 // <= 16 more results fit before the next check
         }
-        res.flush();
-#if RRX_FEED == 1 || RRX_FEED == 2
-#pragma unroll
-        for (int i = 0; i < kSlots; i++) buf[i] = nxt[i];
-#elif RRX_FEED == 3 || RRX_FEED == 4
-        if (more) {
+        // All lanes flush together every 4th round (512 bytes: ~11 lines of typical text fit the 31 result slots).
+        // Every round costs 6 %; leaving it to the overflow check above makes the lanes flush at different
+        // times, so that almost every check diverges: measured slower than either.
+        if ((r & 3) == 3) res.flush();
+        if (r + 1 < rounds) {
 #pragma unroll
             for (int i = 0; i < kSlots; i++) buf[i] = src[(r + 1) * kSlots + i];
         }
-#elif RRX_FEED == 5
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < kSlots / 2; i++) buf[i] = src[(r + 1) * kSlots + i];
-            // consume the first half's registers so that the compiler waits for them here
-            asm volatile("" ::"v"(buf[0].x), "v"(buf[1].x), "v"(buf[2].x), "v"(buf[3].x));
-#pragma unroll
-            for (int i = kSlots / 2; i < kSlots; i++) buf[i] = src[(r + 1) * kSlots + i];
-        }
-#endif
     }
     pos += (size_t)rounds * kRound;
 
