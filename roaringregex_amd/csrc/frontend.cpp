@@ -75,11 +75,10 @@ struct Token {
 };
 
 class Lexer {
-    const std::string &pat;
-    const char *p;
+    const char *p;          // NUL-terminated pattern (the byte rules read the terminator, like the reference does)
     size_t ps;
 public:
-    explicit Lexer(const std::string &s) : pat(s), p(s.c_str()), ps(s.size()) {}
+    explicit Lexer(const std::string &s) : p(s.c_str()), ps(s.size()) {}
 
     // Parser.cpp:16-39.  s0 = index of '['.  Returns the index the cursor is left on.
     size_t bracket(size_t s0, CharSet &set) const {
