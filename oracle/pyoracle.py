@@ -13,13 +13,24 @@ _LIB = None
 
 def build(force=False):
     """Compile liboracle.so (and oracle/_ref when /root/reference is present)."""
+    import fcntl
     so = os.path.join(_HERE, "liboracle.so")
     src = os.path.join(_HERE, "rr_oracle.c")
-    if force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     ref_so = os.path.join(_HERE, "_ref", "libref_bitset.so")
-    if os.path.isdir("/root/reference/src") and (force or not os.path.exists(ref_so)):
-        subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
+
+    def stale():
+        return force or not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src)
+
+    def ref_missing():
+        return os.path.isdir("/root/reference/src") and (force or not os.path.exists(ref_so))
+
+    if stale() or ref_missing():
+        with open(os.path.join(_HERE, ".build.lock"), "w") as lk:      # several processes may get here at once
+            fcntl.flock(lk, fcntl.LOCK_EX)
+            if stale():
+                subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+            if ref_missing():
+                subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
 def lib():

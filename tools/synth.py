@@ -16,7 +16,12 @@ def _lib():
     if _LIB is None:
         so = os.path.join(_HERE, "libsynth.so")
         if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, "synth.c")):
-            subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
+            # several ranks may get here at once: build under an exclusive lock, re-check inside it
+            import fcntl
+            with open(os.path.join(_HERE, ".build.lock"), "w") as lk:
+                fcntl.flock(lk, fcntl.LOCK_EX)
+                if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(os.path.join(_HERE, "synth.c")):
+                    subprocess.check_call(["make", "-C", _HERE], stdout=subprocess.DEVNULL)
         L = C.CDLL(so)
         L.synth_fill.restype = C.c_int
         L.synth_fill.argtypes = [C.c_int, C.c_uint64, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
