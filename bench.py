@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--bytes", type=int, default=0, help="bytes per GPU (default: the BASELINE size)")
     ap.add_argument("--engine", default="auto", choices=["auto", "nfa", "dfa"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stripe", type=int, default=0, help="bytes per GPU lane (0 = chosen from the corpus size)")
     ap.add_argument("--pcie", action="store_true", help="also time the host-buffer entry (upload + index + match + download)")
     args = ap.parse_args()
 
@@ -164,7 +165,7 @@ def main():
         dev[off:off + piece].copy_(torch.from_numpy(host[off:off + piece]))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    corpus = rr.Corpus(dev)
+    corpus = rr.Corpus(dev, stripe=args.stripe)
     torch.cuda.synchronize()
     index_ms = (time.perf_counter() - t0) * 1e3
     nlines = corpus.num_lines
@@ -213,7 +214,7 @@ def main():
             "config": {"workload": "BASELINE %s (%d reference states, %s class) over %.2f GiB synthetic lines per GPU"
                                    % (config_name, regex.states_n, "BitSet<%d>" % regex.set_class if regex.set_class else "Roaring", nbytes / 2**30),
                        "pattern_states": regex.states_n, "useful_states": regex.useful_states, "engine": regex.engine_name,
-                       "bytes_per_gpu": nbytes, "lines_per_gpu": nlines, "accepted_rank0": accepted, "sharding": "by lines, no collective"},
+                       "bytes_per_gpu": nbytes, "stripe_bytes": corpus.stripe, "lines_per_gpu": nlines, "accepted_rank0": accepted, "sharding": "by lines, no collective"},
             "per_gpu_GBs": round(nbytes * args.steps / elapsed / 1e9, 2),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, nbytes),
