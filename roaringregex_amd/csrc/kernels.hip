@@ -572,11 +572,21 @@ __global__ __launch_bounds__(kThreads) void match_extents_kernel(Program prog, c
     e = e - b >= trim ? e - trim : b;
     typename Engine::State st;
     eng.reset(st);
-    for (size_t p = b; p < e; p++) {
-        uint32_t c = bytes[p];
-        if (c == 0 || c >= 0x80) { eng.kill(st); break; }
-        eng.step(st, c);
+    bool dead = false;
+    size_t p = b;
+    auto one = [&](uint32_t c) {
+        if (c == 0 || c >= 0x80) { eng.kill(st); dead = true; }
+        else eng.step(st, c);
+    };
+    for (; p < e && (p & 15) && !dead; p++) one(bytes[p]);                 // up to 16-byte alignment
+    for (; p + 16 <= e && !dead; p += 16) {                                // 16 bytes per load
+        const uint4 v = *reinterpret_cast<const uint4 *>(bytes + p);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+            if (!dead) one((w[k >> 2] >> (8 * (k & 3))) & 0xffu);
     }
+    for (; p < e && !dead; p++) one(bytes[p]);
     accept[i] = eng.accepting(st) ? 1 : 0;
 }
 

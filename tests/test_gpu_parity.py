@@ -335,3 +335,28 @@ def test_match_host_pipeline_equals_resident_path():
     o = OracleRegex(U2)
     piece = host[:1 << 20]
     assert (got[:int((piece == 10).sum())] == o.match_lines(piece)).all()
+
+
+def test_extents_with_unaligned_items_of_many_lengths():
+    """The extents kernel walks items with 16-byte loads between an unaligned head and tail: items of every length
+    0..80 at every alignment, plus a few long ones, with dead bytes sprinkled in."""
+    rng = np.random.default_rng(12)
+    items = []
+    for n in list(range(0, 81)) + [255, 256, 257, 1000, 4097]:
+        body = np.frombuffer(b"ab\n", dtype=np.uint8)[rng.integers(0, 3, size=n)].copy()
+        if n and rng.random() < 0.15:
+            body[rng.integers(0, n)] = rng.choice([0, 0x80, 0xff])
+        items.append(body.tobytes())
+    blob = b"".join(items)
+    off = np.cumsum([0] + [len(i) for i in items]).astype(np.int64)
+    data = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).cuda()
+    offs = torch.from_numpy(off).cuda()
+    p = "(a|b|\n)*ab(a|\n)*"
+    o = OracleRegex("(a|b|x)*ab(a|x)*")        # the oracle API is NUL/newline-agnostic: model '\n' as 'x'
+    want = []
+    for it in items:
+        t = it.replace(b"\n", b"x")
+        want.append(int(o.accepts(t)))
+    for r in engines_for(p, small=True):
+        got = r.match_extents(data, offs).cpu().numpy()
+        assert list(got) == want, r.engine_name
