@@ -105,6 +105,12 @@ struct rrx_regex {
             const bool wide = line_wide;
             uint32_t stride = wide ? dev::kWideColumns : (K + 1);
             if (!wide && !(stride & 1)) stride++;                       // odd row stride spreads rows over LDS banks
+            // Wide form: R = 2^rep interleaved copies (copy k of logical dword i at dword i*R + k), lane l reads copy
+            // l % R: its reads only touch LDS banks = l (mod R), so a half-wave splits into R groups that cannot
+            // conflict with each other.  Row byte offsets must stay 16-bit: D * stride * 4 * R <= 65536.
+            uint32_t rep = 0;
+            if (wide && !line_global) while (rep < 5 && (size_t)D * stride * 4 * (2u << rep) <= 65536) rep++;
+            const uint32_t R = 1u << rep;
             std::vector<uint32_t> T((size_t)D * stride, 0);
             uint8_t lcls[256];
             for (int c = 0; c < 256; c++) lcls[c] = dfa.cls[c];
@@ -123,9 +129,16 @@ struct rrx_regex {
                     row[K] = nl_entry;
                 }
             }
+            if (R > 1) {                                                 // interleave the copies; offsets scale by R
+                std::vector<uint32_t> TR(T.size() * R);
+                for (size_t i = 0; i < T.size(); i++)
+                    for (uint32_t k = 0; k < R; k++) TR[i * R + k] = (T[i] & 0xffffu) * R + 4 * k + (T[i] & 0xffff0000u);
+                T.swap(TR);
+            }
             oT = put(T.data(), T.size() * 4);
             oL = put(lcls, 256);
-            t.line.nrows = D; t.line.stride = stride; t.line.start_off = dfa.start * row_bytes; t.line.wide = wide ? 1 : 0;
+            t.line.nrows = D; t.line.stride = stride * R; t.line.start_off = dfa.start * row_bytes * R; t.line.wide = wide ? 1 : 0;
+            t.line.rep_log2 = rep;
             t.line.in_global = line_global ? 1 : 0;
         }
         HIP_TRY(hipMalloc(&t.blob, host.size() + 16));

@@ -13,13 +13,14 @@ namespace dev {
 #define RRX_THREADS 1024
 #endif
 constexpr int kThreads = RRX_THREADS;       // lanes per workgroup: one LDS copy of the tables serves them all
-// Stripe = bytes per lane: a per-corpus power of two in [kMinStripe, kMaxStripe], chosen so that a corpus
-// yields about half a million lanes (big stripes amortise the per-stripe work: following the straddling line,
-// the final flush; small ones keep every CU busy on a small corpus).
-constexpr uint32_t kMinStripe = 1024, kMaxStripe = 16384;
-constexpr size_t kTargetLanes = (size_t)1 << 19;
+// Stripe = bytes per lane: a per-corpus power of two.  Measured on the final kernel: several generations of waves
+// per CU beat one generation of long-lived waves (the early finishers' slots get refilled while the slowest waves
+// drain), until the per-stripe work (following the straddling line, the final flush) shows: 4 KiB is best at 8 GiB,
+// 2 KiB at 1 GiB.  Automatic choice: about two million lanes, between 2 KiB and 16 KiB; explicit: 1-16 KiB.
+constexpr uint32_t kMinStripe = 1024, kMaxStripe = 16384, kMinAutoStripe = 2048;
+constexpr size_t kTargetLanes = (size_t)1 << 21;
 inline uint32_t pick_stripe(size_t nbytes) {
-    uint32_t s = kMinStripe;
+    uint32_t s = kMinAutoStripe;
     while (s < kMaxStripe && nbytes / s > kTargetLanes) s *= 2;
     return s;
 }
@@ -66,6 +67,9 @@ struct LineDfaDevice {
     uint32_t stride = 0;                         // entries per row
     uint32_t start_off = 0;                      // byte offset of the start row
     uint32_t wide = 0;                           // 1: columns are byte values (kWideColumns); 0: byte classes
+    uint32_t rep_log2 = 0;                       // wide form: 2^rep_log2 copies of the table interleaved dword by dword
+                                                 //   (entry of copy k for logical dword i at dword i*R + k); lane l
+                                                 //   reads copy l % R, i.e. only LDS banks congruent to l mod R
     uint32_t in_global = 0;                      // 1: table too large for LDS, read from HBM/L2; entry = next row's
                                                  //    first-entry index (24 bits) | nl << 30 | accept << 31
     const uint32_t *table = nullptr;             // [nrows][stride]

@@ -44,6 +44,7 @@ struct LineDfaEngine {
     const uint8_t *tab;                    // LDS, byte-addressed
     const uint8_t *cls;                    // LDS [256] (classed form)
     uint32_t start_off, dead_off;
+    uint32_t col_shift;                    // log2(bytes between neighbouring columns) = 2 + log2(copies)
 
     static size_t lds_bytes(const LineDfaDevice &p) { return (size_t)p.nrows * p.stride * 4 + (WIDE ? 0 : 256); }
     typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
@@ -62,8 +63,11 @@ struct LineDfaEngine {
             cls = c;
         }
         tab = lds;
-        start_off = p.start_off + base;
-        dead_off = base;
+        // R interleaved copies (wide form): lane l lives in copy l % R, whose dwords sit in banks = l (mod R)
+        const uint32_t copy = WIDE ? (threadIdx.x & ((1u << p.rep_log2) - 1u)) * 4u : 0u;
+        col_shift = 2u + (WIDE ? p.rep_log2 : 0u);
+        start_off = p.start_off + base + copy;
+        dead_off = base + copy;
     }
     __device__ __forceinline__ State fresh() const { return State{start_off}; }
     __device__ __forceinline__ State skipping() const { return State{dead_off}; }   // dead row: waits for '\n'
@@ -79,7 +83,7 @@ struct LineDfaEngine {
     __device__ __forceinline__ void consume(State &st, uint32_t w, uint32_t &bits) const {
         if constexpr (WIDE && !CLAMP) {
 #ifdef RRX_PROBE_NO_LOOKUP      /* measurement only: no table read (results are wrong) */
-            st.e = (st.e + ((w >> (8 * K)) & 0xffu) * 4u) & 0x1ffffu;
+            st.e = (st.e + (((w >> (8 * K)) & 0xffu) << col_shift)) & 0x1ffffu;
             bits = (bits << ((st.e >> 16) & 1u)) | (st.e >> 24);
 #else
             // One asm block per byte (separate statements made hipcc pad every byte with an s_nop).  The block
@@ -93,7 +97,7 @@ struct LineDfaEngine {
                          "v_lshlrev_b32_sdwa %[b], %[e], %[b] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n\t"     \
                          "v_or_b32_sdwa %[b], %[e], %[b] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD"              \
                          : [e] "+v"(st.e), [b] "+v"(bits), [c4] "=&v"(t0), [ad] "=&v"(t1)                                               \
-                         : [w] "v"(w), [two] "v"(2u)                                                                                    \
+                         : [w] "v"(w), [two] "v"(col_shift)                                                                             \
                          : "memory")
             if constexpr (K == 0) RRX_STEP("BYTE_0");
             if constexpr (K == 1) RRX_STEP("BYTE_1");
@@ -116,7 +120,7 @@ struct LineDfaEngine {
         nl = col == 10u ? 1u : 0u;
         acc = st.e & nl;
 #else
-        const uint32_t off = (st.e & 0xffffu) + (col << 2);              // (absolute LDS address in the SDWA form)
+        const uint32_t off = (st.e & 0xffffu) + (col << col_shift);      // (absolute LDS address in the SDWA form)
         st.e = (WIDE && !CLAMP) ? *reinterpret_cast<lds_u32_ptr>(off) : *reinterpret_cast<const uint32_t *>(tab + off);
         nl = (st.e >> 16) & 0xffu;
         acc = st.e >> 24;
