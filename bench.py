@@ -115,7 +115,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="url", choices=sorted(WORKLOADS))
     ap.add_argument("--bytes", type=int, default=0, help="bytes per GPU (default: the BASELINE size)")
-    ap.add_argument("--engine", default="auto", choices=["auto", "nfa", "dfa"])
+    ap.add_argument("--engine", default="auto", choices=["auto", "nfa", "dfa", "dfa2"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stripe", type=int, default=0, help="bytes per GPU lane (0 = chosen from the corpus size)")
     ap.add_argument("--pcie", action="store_true", help="also time the host-buffer entry (upload + index + match + download)")
@@ -150,7 +150,7 @@ def main():
     kind, pkey, default_bytes, config_name = WORKLOADS[args.workload]
     nbytes = args.bytes or default_bytes
     pattern = patterns()[pkey]
-    engine = {"auto": rr.ENGINE_AUTO, "nfa": rr.ENGINE_NFA, "dfa": rr.ENGINE_DFA}[args.engine]
+    engine = {"auto": rr.ENGINE_AUTO, "nfa": rr.ENGINE_NFA, "dfa": rr.ENGINE_DFA, "dfa2": rr.ENGINE_DFA2}[args.engine]
     regex = rr.RRegex(pattern, engine, device=local_rank)
 
     # ---- synthetic shard of this rank (seed differs per rank), generated on the host cores, then resident in HBM

@@ -28,7 +28,8 @@ enum { RRX_OK = 0, RRX_ERR_PATTERN = 1, RRX_ERR_ARG = 2, RRX_ERR_HIP = 3, RRX_ER
 
 /* engine selection for rrx_compile_ex */
 enum { RRX_ENGINE_AUTO = 0, RRX_ENGINE_NFA = 1, RRX_ENGINE_DFA = 2, RRX_ENGINE_DFA_GLOBAL = 3 /* table kept in HBM/L2 */,
-       RRX_ENGINE_NFA_WAVE = 4 /* state set spread over the 64 lanes of a wave: up to 4096 positions */ };
+       RRX_ENGINE_NFA_WAVE = 4 /* state set spread over the 64 lanes of a wave: up to 4096 positions */,
+       RRX_ENGINE_DFA2 = 5 /* table with one dependent lookup per two bytes (AUTO prefers it when it fits) */ };
 
 /* ---- compile: RRegex::RRegex(const char*), Parser.cpp:161-170 (host only, no device needed) ---------- */
 int rrx_compile(const char *pattern, rrx_regex **out);

@@ -13,7 +13,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("RRX_LIB") or os.path.join(_HERE, "librrx.so")   # RRX_LIB: A/B builds of the same ABI
 
-ENGINE_AUTO, ENGINE_NFA, ENGINE_DFA, ENGINE_DFA_GLOBAL, ENGINE_NFA_WAVE = 0, 1, 2, 3, 4
+ENGINE_AUTO, ENGINE_NFA, ENGINE_DFA, ENGINE_DFA_GLOBAL, ENGINE_NFA_WAVE, ENGINE_DFA2 = 0, 1, 2, 3, 4, 5
 
 # every symbol include/rrx.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = (

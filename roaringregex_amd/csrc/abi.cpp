@@ -33,6 +33,7 @@ struct DeviceTables {
     dev::DfaDevice dfa;          // plain form (extents kernel)
     dev::LineDfaDevice line;     // line-mode form (batch kernel)
     dev::WaveNfaDevice wave;     // wave-cooperative NFA
+    dev::Dfa2Device dfa2;        // stride-2 line-mode table (corpora without bytes >= 0x80)
 };
 
 int instantiated_width(uint32_t W) { return W <= 4 ? (int)W : W <= 6 ? 6 : W <= 8 ? 8 : W <= 12 ? 12 : 16; }
@@ -48,6 +49,8 @@ struct rrx_regex {
     NfaProgram nfa_wave;         // up to 4096 positions, no carry groups (wave-cooperative engine)
     bool has_wave = false;
     DfaProgram dfa;
+    Dfa2Program dfa2;
+    bool has_dfa2 = false;
     int engine = 0;
     bool line_wide = false;      // DFA engine: byte-indexed rows (<= kWideMaxStates states) or class-indexed rows
     bool line_global = false;    // DFA engine: class-indexed table too large for LDS, kept in global memory
@@ -67,7 +70,7 @@ struct rrx_regex {
         DeviceTables t;
         std::vector<uint8_t> host;
         auto put = [&](const void *p, size_t n) { size_t off = (host.size() + 15) & ~(size_t)15; host.resize(off + n); std::memcpy(host.data() + off, p, n); return off; };
-        size_t oB = 0, oX = 0, oC = 0, oN = 0, oA = 0, oT = 0, oL = 0;
+        size_t oB = 0, oX = 0, oC = 0, oN = 0, oA = 0, oT = 0, oL = 0, oP2 = 0, oT2 = 0;
         size_t oM = 0;
         if (engine == RRX_ENGINE_NFA_WAVE) {
             const uint32_t W = nfa_wave.W, WP = dev::kWaveWords;
@@ -137,6 +140,27 @@ struct rrx_regex {
             }
             oT = put(T.data(), T.size() * 4);
             oL = put(lcls, 256);
+            if (has_dfa2) {
+                // stride-2 tables: T2 rows of `s2` entries (odd), R interleaved copies, P = swizzled pair -> column offset
+                const uint32_t D2 = dfa2.nstates, C2 = dfa2.ncols;
+                uint32_t s2 = C2 | 1u;
+                uint32_t rep2 = 0;
+                while (rep2 < 5 && (size_t)D2 * s2 * 4 * (2u << rep2) <= dev::kDfa2TableBudget && (size_t)C2 * 4 * (2u << rep2) <= 65535) rep2++;
+                const uint32_t R2 = 1u << rep2;
+                std::vector<uint32_t> T2((size_t)D2 * s2 * R2, 0);
+                for (uint32_t st = 0; st < D2; st++)
+                    for (uint32_t col = 0; col < C2; col++) {
+                        const uint32_t v = dfa2.next2[(size_t)st * C2 + col];
+                        const uint32_t row_off = (v & 0xffffu) * s2 * 4 * R2;
+                        for (uint32_t k = 0; k < R2; k++) T2[((size_t)st * s2 + col) * R2 + k] = (row_off + 4 * k) | (v & 0xffff0000u);
+                    }
+                std::vector<uint16_t> P(128 * dev::kDfa2PStride, 0);
+                for (unsigned c1 = 0; c1 < 128; c1++)
+                    for (unsigned c2 = 0; c2 < 128; c2++) P[c1 * dev::kDfa2PStride + c2] = (uint16_t)(dfa2.pair_col[c1 * 128 + c2] * 4 * R2);
+                oP2 = put(P.data(), P.size() * 2);
+                oT2 = put(T2.data(), T2.size() * 4);
+                t.dfa2.nrows = D2; t.dfa2.stride = s2 * R2; t.dfa2.start_off = dfa2.start * s2 * 4 * R2; t.dfa2.rep_log2 = rep2;
+            }
             t.line.nrows = D; t.line.stride = stride * R; t.line.start_off = dfa.start * row_bytes * R; t.line.wide = wide ? 1 : 0;
             t.line.rep_log2 = rep;
             t.line.in_global = line_global ? 1 : 0;
@@ -157,6 +181,10 @@ struct rrx_regex {
             t.dfa.acc = base + oA;
             t.line.table = reinterpret_cast<const uint32_t *>(base + oT);
             t.line.cls = base + oL;
+            if (has_dfa2) {
+                t.dfa2.P = reinterpret_cast<const uint16_t *>(base + oP2);
+                t.dfa2.T2 = reinterpret_cast<const uint32_t *>(base + oT2);
+            }
         }
         auto ins = on_device.emplace(device, t);
         *out = &ins.first->second;
@@ -180,7 +208,7 @@ const char *rrx_last_error(void) { return g_err.c_str(); }
 
 int rrx_compile_ex(const char *pattern, int engine, rrx_regex **out) {
     if (!pattern || !out) return fail(RRX_ERR_ARG, "null argument");
-    if (engine < RRX_ENGINE_AUTO || engine > RRX_ENGINE_NFA_WAVE) return fail(RRX_ERR_ARG, "unknown engine");
+    if (engine < RRX_ENGINE_AUTO || engine > RRX_ENGINE_DFA2) return fail(RRX_ERR_ARG, "unknown engine");
     *out = nullptr;
     rrx_regex *re = new rrx_regex();
     try {
@@ -189,13 +217,18 @@ int rrx_compile_ex(const char *pattern, int engine, rrx_regex **out) {
         re->trimmed = trim(re->ref);
         const Reduced red = reduce(re->trimmed);
         if (engine == RRX_ENGINE_AUTO || engine == RRX_ENGINE_NFA) re->has_nfa = lower_nfa(red, dev::kMaxNfaWords * 32, re->nfa);
-        if (engine != RRX_ENGINE_NFA && engine != RRX_ENGINE_NFA_WAVE) {
+        if (engine != RRX_ENGINE_NFA && engine != RRX_ENGINE_NFA_WAVE) {     // (DFA, DFA_GLOBAL, DFA2, AUTO)
             re->has_dfa = lower_dfa(red, kMaxSubsetStates, re->dfa);
             if (re->has_dfa) {
                 re->line_wide = re->dfa.nstates <= dev::kWideMaxStates && engine != RRX_ENGINE_DFA_GLOBAL;
                 const size_t classed_entries = (size_t)re->dfa.nstates * (re->dfa.ncls + 2);
                 re->line_global = engine == RRX_ENGINE_DFA_GLOBAL || (!re->line_wide && classed_entries > dev::kClassedMaxEntries);
                 if (re->line_global && classed_entries >= ((size_t)1 << 24)) re->has_dfa = false;
+                // stride-2 form: when the table (rows of distinct pair columns) fits next to the 32 KiB pair table
+                if (re->has_dfa && !re->line_global && engine != RRX_ENGINE_DFA && re->dfa.nstates <= 4096) {
+                    re->has_dfa2 = lower_dfa2(re->dfa, 1024, re->dfa2) &&
+                                   (size_t)re->dfa2.nstates * (re->dfa2.ncols | 1u) * 4 <= dev::kDfa2TableBudget;
+                }
             }
         }
         // the wave-cooperative form: when asked for, or as the last resort of AUTO
@@ -212,6 +245,7 @@ int rrx_compile_ex(const char *pattern, int engine, rrx_regex **out) {
     if (engine == RRX_ENGINE_NFA) re->engine = re->has_nfa ? RRX_ENGINE_NFA : 0;
     else if (engine == RRX_ENGINE_DFA || engine == RRX_ENGINE_DFA_GLOBAL) re->engine = re->has_dfa ? RRX_ENGINE_DFA : 0;
     else if (engine == RRX_ENGINE_NFA_WAVE) re->engine = re->has_wave ? RRX_ENGINE_NFA_WAVE : 0;
+    else if (engine == RRX_ENGINE_DFA2) re->engine = re->has_dfa2 ? RRX_ENGINE_DFA : 0;
     else re->engine = (re->has_dfa && !re->line_global) ? RRX_ENGINE_DFA : re->has_nfa ? RRX_ENGINE_NFA : re->has_dfa ? RRX_ENGINE_DFA
                       : re->has_wave ? RRX_ENGINE_NFA_WAVE : 0;
     if (!re->engine) {
@@ -239,6 +273,7 @@ int rrx_engine(const rrx_regex *re) { return re->engine; }
 const char *rrx_engine_name(const rrx_regex *re) {
     if (re->engine == RRX_ENGINE_NFA_WAVE) return "nfa-wave-cooperative";
     if (re->engine != RRX_ENGINE_DFA) return "nfa-shift-and";
+    if (re->has_dfa2) return "dfa-stride2-table";      // (the byte-stride table still serves corpora with bytes >= 0x80)
     return re->line_global ? "dfa-global-table" : re->line_wide ? "dfa-wide-table" : "dfa-classed-table";
 }
 uint32_t rrx_useful_states(const rrx_regex *re) { return re->trimmed.n; }
@@ -252,6 +287,11 @@ size_t rrx_program_words(const rrx_regex *re, int kind, uint32_t *out, size_t ca
         const NfaProgram &p = kind == RRX_ENGINE_NFA ? re->nfa : re->nfa_wave;
         w = {p.W, p.nbits, p.n_exc, p.accepts_empty ? 1u : 0u};
         for (auto *v : {&p.init, &p.fin, &p.chain, &p.self, &p.excm, &p.cgrp, &p.ctgt, &p.B, &p.X}) w.insert(w.end(), v->begin(), v->end());
+    } else if (kind == RRX_ENGINE_DFA2 && re->has_dfa2) {
+        const Dfa2Program &d = re->dfa2;
+        w = {d.nstates, d.ncols, d.start, d.accepts_empty ? 1u : 0u};
+        for (uint16_t c : d.pair_col) w.push_back(c);
+        w.insert(w.end(), d.next2.begin(), d.next2.end());
     } else if (kind == RRX_ENGINE_DFA && re->has_dfa) {
         const DfaProgram &d = re->dfa;
         w = {d.nstates, d.ncls, d.start, d.accepts_empty ? 1u : 0u};
@@ -328,6 +368,8 @@ int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accep
                 ? dev::match_stripes_wave_nfa(t->wave, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream)
             : re->engine == RRX_ENGINE_NFA
                 ? dev::match_stripes_nfa(t->nfa, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream)
+            : (re->has_dfa2 && !c->has_high)
+                ? dev::match_stripes_dfa2(t->dfa2, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream)
                 : dev::match_stripes_dfa(t->line, c->has_high, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream);
     if (e) return hip_fail((hipError_t)e, "match_stripes launch");
     return RRX_OK;

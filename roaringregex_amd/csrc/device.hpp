@@ -76,6 +76,25 @@ struct LineDfaDevice {
     const uint8_t *cls = nullptr;                // [256] (classed form only)
 };
 
+// Stride-2 line-mode table: one dependent lookup per TWO bytes.  The column of a byte pair comes from the
+// state-independent table P (resolved off the critical path); T2[row][column] = next row after both bytes, with
+// the number of lines that ended inside the pair (0..2) and their verdicts (oldest highest).
+//   P  : u16 [128][130], P[c1*130 + c2] = byte offset of the pair's column inside a T2 row (row stride 130 = 65
+//        words: the LDS bank is (c1 + c2/2) mod 32, it depends on both bytes); only for corpora without bytes >= 0x80
+//   T2 : u32 [nrows][stride], entry = LDS address of the next row (16 bits) | lines << 16 | verdicts << 24,
+//        2^rep_log2 interleaved copies like the wide table
+struct Dfa2Device {
+    uint32_t nrows = 0, stride = 0, start_off = 0, rep_log2 = 0;
+    const uint16_t *P = nullptr;
+    const uint32_t *T2 = nullptr;
+};
+constexpr uint32_t kDfa2PStride = 130;                // u16 entries per P row
+constexpr uint32_t kDfa2PBytes = 128 * kDfa2PStride * 2;
+constexpr uint32_t kDfa2TableBudget = 31 * 1024;     // P (32.5 KiB) + T2 <= 64 KiB: two 1024-lane workgroups per CU
+
+int match_stripes_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
+                       size_t nstripes, uint32_t *accept_bits, void *stream);
+
 // All launchers are asynchronous on `stream` and return a hipError_t value (0 = success).
 int count_newlines_per_stripe(const uint8_t *bytes, size_t nbytes, uint32_t stripe, uint32_t *counts, size_t nstripes, uint32_t *flags, void *stream);
 int scan_counts(const uint32_t *counts, uint64_t *base, uint64_t *chunk_sums, size_t n, void *stream);   // base[n] = total

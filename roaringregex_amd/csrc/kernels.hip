@@ -427,6 +427,156 @@ __global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, c
     res.finish();
 }
 
+// ============================================================================================ stride-2 table kernel
+// The per-byte table step is bounded by the latency of its dependent LDS round trip (add -> ds_read -> wait, ~210
+// cycles at 8 chains per SIMD).  Here ONE dependent lookup consumes TWO bytes: the pair's column comes from the
+// state-independent table P (its read does not wait for the state), then e = T2[row(e)][column].  U2: 46 distinct
+// pair columns of 289 class pairs, T2 = 16 KiB.  Per pair: 6 VALU + 2 LDS reads (3 VALU per byte).
+struct Dfa2 {
+    typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
+    struct State { uint32_t e; };          // low 16 bits = LDS address of the current row (of this lane's copy)
+    const uint16_t *P;                     // LDS (a static array at a link-time address: no base to add per pair)
+    uint32_t start_off, dead_off;
+
+    static size_t lds_bytes(const Dfa2Device &p) { return (size_t)p.nrows * p.stride * 4; }     // dynamic part: T2
+    __device__ void load(const Dfa2Device &p, uint16_t *p_lds, uint8_t *t_lds) {
+        uint32_t *pl = reinterpret_cast<uint32_t *>(p_lds);
+        const uint32_t *ps = reinterpret_cast<const uint32_t *>(p.P);
+        for (int i = threadIdx.x; i < (int)(kDfa2PBytes / 4); i += blockDim.x) pl[i] = ps[i];
+        uint32_t *t = reinterpret_cast<uint32_t *>(t_lds);
+        const uint32_t tbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)t_lds;
+        const int n = (int)(p.nrows * p.stride);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) t[i] = p.T2[i] + tbase;
+        const uint32_t copy = (threadIdx.x & ((1u << p.rep_log2) - 1u)) * 4u;
+        P = p_lds;
+        start_off = p.start_off + tbase + copy;
+        dead_off = tbase + copy;
+    }
+    __device__ __forceinline__ State fresh() const { return State{start_off}; }
+    __device__ __forceinline__ State skipping() const { return State{dead_off}; }
+    // generic pair step (tails and the walk past the stripe end)
+    __device__ __forceinline__ void step2(State &st, uint32_t c1, uint32_t c2, uint32_t &lines, uint32_t &verdicts) const {
+        const uint32_t col = P[c1 * kDfa2PStride + c2];
+        st.e = *reinterpret_cast<lds_u32_ptr>((st.e & 0xffffu) + col);
+        lines = (st.e >> 16) & 0xffu;
+        verdicts = st.e >> 24;
+    }
+    // the four bytes of text word w (two pairs), fused with bits = (bits << lines) | verdicts.  Per pair:
+    //     t    = (2 c1) * 130                v_mul_u32_u24_sdwa   src0_sel:BYTE_even
+    //     idx  = t + 2 c2                    v_add_u32_sdwa       src1_sel:BYTE_odd        (byte offset into P)
+    //     col  = P[idx]                      ds_read_u16                                   (does not wait for the state)
+    //     addr = e.word[0] + col             v_add_u32_sdwa       src0_sel:WORD_0
+    //     e    = LDS[addr]                   ds_read_b32
+    //     bits = (bits << e.byte[2]) | e.byte[3]                 2 x SDWA
+    __device__ __forceinline__ void consume_dword(State &st, uint32_t w, uint32_t &bits) const {
+        const uint32_t w2 = w << 1;                      // every byte < 0x80: doubling stays inside the byte
+        const uint32_t stride = kDfa2PStride;
+        uint32_t ta, ia, tb, ib;
+        asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(ta) : "v"(w2), "v"(stride));
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(ia) : "v"(ta), "v"(w2));
+        asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(tb) : "v"(w2), "v"(stride));
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(ib) : "v"(tb), "v"(w2));
+        const uint32_t ca = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(P) + ia);
+        const uint32_t cb = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(P) + ib);
+        uint32_t addr;
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(addr) : "v"(st.e), "v"(ca));
+        st.e = *reinterpret_cast<lds_u32_ptr>(addr);
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(bits) : "v"(st.e), "v"(bits));
+        asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(bits) : "v"(st.e), "v"(bits));
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(addr) : "v"(st.e), "v"(cb));
+        st.e = *reinterpret_cast<lds_u32_ptr>(addr);
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(bits) : "v"(st.e), "v"(bits));
+        asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(bits) : "v"(st.e), "v"(bits));
+    }
+};
+
+// Same stripe geometry, feed and result path as match_stripes_kernel; pairs are aligned to even byte positions
+// (stripes are even-sized), a line end may fall on either byte of a pair.
+__global__ __launch_bounds__(kThreads) void match_stripes2_kernel(Dfa2Device prog, const uint8_t *__restrict__ bytes, size_t nbytes,
+                                                                   uint32_t stripe, const uint64_t *__restrict__ stripe_base,
+                                                                   uint32_t *__restrict__ accept_bits) {
+    __shared__ __attribute__((aligned(16))) uint16_t p_lds[kDfa2PBytes / 2];     // 33,280 bytes: a multiple of 16
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    Dfa2 eng;
+    eng.load(prog, p_lds, smem);
+    __syncthreads();
+
+    const size_t g = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    const size_t start = g * (size_t)stripe;
+    if (start >= nbytes) return;
+    const size_t stripe_end = start + stripe;
+    const size_t my_end = stripe_end < nbytes ? stripe_end : nbytes;
+    const bool fresh = start == 0 || bytes[start - 1] == '\n';
+    Dfa2::State st = fresh ? eng.fresh() : eng.skipping();
+    Results res;
+    res.begin(stripe_base[g], !fresh, accept_bits);
+
+    size_t pos = start;
+    const uint4 *src = reinterpret_cast<const uint4 *>(bytes + start);
+    constexpr int kSlots = kRound / 16;
+    const int rounds = (int)((my_end - start) / kRound);
+    uint4 buf[kSlots];
+    if (rounds > 0) {
+#pragma unroll
+        for (int i = 0; i < kSlots; i++) buf[i] = src[i];
+    }
+    for (int r = 0; r < rounds; r++) {
+#pragma unroll
+        for (int i = 0; i < kSlots; i++) {
+            eng.consume_dword(st, buf[i].x, res.bits);
+            eng.consume_dword(st, buf[i].y, res.bits);
+            eng.consume_dword(st, buf[i].z, res.bits);
+            eng.consume_dword(st, buf[i].w, res.bits);
+            if (res.bits >> 15) res.flush();                 // <= 16 more results fit before the next check
+        }
+        if ((r & 3) == 3) res.flush();
+        if (r + 1 < rounds) {
+#pragma unroll
+            for (int i = 0; i < kSlots; i++) buf[i] = src[(r + 1) * kSlots + i];
+        }
+    }
+    pos += (size_t)rounds * kRound;
+
+    // ---- tail of the corpus inside my stripe (only the last stripe has one): whole pairs, then an odd last byte.
+    // The odd byte is paired with a virtual '\n': if it is a '\n' itself the pair reports two line ends, of which
+    // only the first exists; otherwise the virtual '\n' is the end of data ending the last line, and the walk
+    // below must not end it again.
+    bool closed_by_end_of_data = false;
+    for (; pos + 2 <= my_end; pos += 2) {
+        uint32_t lines, verdicts;
+        eng.step2(st, bytes[pos], bytes[pos + 1], lines, verdicts);
+        res.bits = (res.bits << lines) | verdicts;
+        if (res.bits >> 29) res.flush();
+    }
+    if (pos < my_end) {
+        const uint32_t b = bytes[pos];
+        uint32_t lines, verdicts;
+        eng.step2(st, b, '\n', lines, verdicts);
+        if (b == '\n') res.push(1, verdicts >> 1);
+        else { res.push(1, verdicts); closed_by_end_of_data = true; }
+        pos++;
+    }
+    res.flush();
+
+    // ---- follow my last line past the stripe end (same ownership rule as the byte kernel), pair by pair
+    const bool started = fresh || res.seen > 0;
+    if (!closed_by_end_of_data && started && bytes[my_end - 1] != '\n') {
+        uint32_t lines = 0, verdicts = 0;
+        while (pos + 16 <= nbytes && !lines) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(bytes + pos);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (!lines) eng.step2(st, (w[k >> 1] >> (16 * (k & 1))) & 0xffu, (w[k >> 1] >> (16 * (k & 1) + 8)) & 0xffu, lines, verdicts);
+            pos += 16;
+        }
+        for (; pos + 2 <= nbytes && !lines; pos += 2) eng.step2(st, bytes[pos], bytes[pos + 1], lines, verdicts);
+        if (!lines) eng.step2(st, pos < nbytes ? bytes[pos] : '\n', '\n', lines, verdicts);   // end of data ends the line
+        res.push(1, lines == 2 ? verdicts >> 1 : verdicts);     // only the first line end of the pair is mine
+    }
+    res.finish();
+}
+
 // ============================================================================================ wave-cooperative NFA
 // For automata too large for one lane's registers: the 64 lanes of a wave hold ONE state set, lane l the
 // positions [64 l, 64 l + 64) as two 32-bit words.  A wave walks the lines that start in its stripe one byte
@@ -786,6 +936,16 @@ int match_extents_wave_nfa(const WaveNfaDevice &p, const uint8_t *bytes, const u
     if (!nitems) return 0;
     size_t blocks = (nitems + 3) / 4;
     hipLaunchKernelGGL(match_extents_wave_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, p, bytes, off, nitems, trim, accept);
+    return (int)hipGetLastError();
+}
+int match_stripes_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
+                       size_t nstripes, uint32_t *accept, void *stream) {
+    if (!nstripes) return 0;
+    const size_t lds = Dfa2::lds_bytes(p);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(match_stripes2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    size_t blocks = (nstripes + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(match_stripes2_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept);
     return (int)hipGetLastError();
 }
 int match_extents_nfa(const NfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim, uint8_t *accept,

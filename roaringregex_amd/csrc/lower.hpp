@@ -64,6 +64,17 @@ struct DfaProgram {
     bool accepts_empty = false;
 };
 
+// Stride-2 form of a DfaProgram: one step consumes two bytes.  Symbols are the byte classes plus '\n' (which ends
+// a line: verdict of the state, restart).  Pairs of symbols with identical behaviour on every state share a column.
+struct Dfa2Program {
+    uint32_t nstates = 0, ncols = 0, start = 0;
+    std::vector<uint16_t> pair_col;         // [128][128]: column of the byte pair (c1, c2)
+    std::vector<uint32_t> next2;            // [nstates][ncols]: next state | lines ended (0..2) << 16 | verdicts << 24
+    bool accepts_empty = false;             //   (verdicts: oldest line highest)
+};
+// Returns false if there are more than max_cols distinct pair columns.
+bool lower_dfa2(const DfaProgram &d, uint32_t max_cols, Dfa2Program &out);
+
 // The trimmed automaton re-expressed over "positions" (a state split by the character set it is entered on; node 0
 // = the initial state before any input), shrunk by bisimulation quotients and pruning of dominated edges.
 // Both device programs are lowered from this one graph.

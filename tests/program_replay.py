@@ -53,3 +53,32 @@ class DfaReplay:
                 return False
             st = int(self.next[st, self.cls[c]])
         return bool(self.acc[st])
+
+
+class Dfa2Replay:
+    """Stride-2 line-mode table (rrx_program_words kind 5): [D, C, start, accepts_empty, pair_col[128*128], next2[D][C]];
+    next2 entry = next state | lines ended in the pair << 16 | their verdicts << 24 (oldest highest)."""
+
+    def __init__(self, words):
+        w = np.asarray(words, dtype=np.int64)
+        self.D, self.C, self.start = int(w[0]), int(w[1]), int(w[2])
+        self.pair_col = w[4:4 + 16384]
+        self.next2 = w[4 + 16384:].reshape(self.D, self.C)
+
+    def match_lines(self, data):
+        """Verdict per '\\n'-delimited line of `data` (bytes < 0x80 only), stepping two bytes at a time."""
+        seq = bytearray(data)
+        if not seq:
+            return []
+        if seq[-1] != 10:
+            seq.append(10)                       # end of data ends the last line
+        drop_last = len(seq) % 2 == 1
+        if drop_last:
+            seq.append(10)                       # padding: produces one spurious empty line
+        out, st = [], self.start
+        for i in range(0, len(seq), 2):
+            e = int(self.next2[st, self.pair_col[seq[i] * 128 + seq[i + 1]]])
+            st, lines, verdicts = e & 0xffff, (e >> 16) & 0xff, e >> 24
+            for k in range(lines):
+                out.append((verdicts >> (lines - 1 - k)) & 1)
+        return out[:-1] if drop_last else out

@@ -19,4 +19,4 @@ def test_header_and_library_agree():
 
 def test_compile_needs_no_device():
     r = rr.RRegex("ab*c")
-    assert r.states_n == 6 and r.engine_name in ("dfa-wide-table", "dfa-classed-table", "nfa-shift-and")
+    assert r.states_n == 6 and r.engine_name in ("dfa-stride2-table", "dfa-wide-table", "dfa-classed-table", "nfa-shift-and")

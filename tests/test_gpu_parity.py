@@ -25,7 +25,7 @@ def engines_for(pattern, small=False):
     """One compiled regex per device engine that admits the automaton.  The wave-cooperative NFA runs one string
     per wave (tens of MB/s), so it only joins on small inputs."""
     out = []
-    kinds = [rr.ENGINE_NFA, rr.ENGINE_DFA, rr.ENGINE_DFA_GLOBAL] + ([rr.ENGINE_NFA_WAVE] if small else [])
+    kinds = [rr.ENGINE_NFA, rr.ENGINE_DFA, rr.ENGINE_DFA2, rr.ENGINE_DFA_GLOBAL] + ([rr.ENGINE_NFA_WAVE] if small else [])
     for e in kinds:
         try:
             out.append(rr.RRegex(pattern, e))

@@ -6,7 +6,7 @@ import pytest
 
 import roaringregex_amd as rr
 from patterns import EMAIL, K1000, K1000_CONTAINS, KAT, U2, random_pattern, strings_near
-from program_replay import DfaReplay, NfaReplay
+from program_replay import Dfa2Replay, DfaReplay, NfaReplay
 from pyoracle import OracleError, OracleRegex
 
 
@@ -144,7 +144,7 @@ def test_reduction_statistics():
     w = r.program(rr.ENGINE_NFA)
     assert w[1] == 86 and w[2] == 0           # a pure shift chain: no exception rows
     r = rr.RRegex(K1000)
-    assert r.states_n == 7786 and r.engine == rr.ENGINE_DFA
+    assert r.states_n == 7786 and r.engine == rr.ENGINE_DFA and r.engine_name == "dfa-stride2-table"
 
 
 def test_wave_program_for_automata_beyond_one_lane():
@@ -169,3 +169,38 @@ def test_wave_program_for_automata_beyond_one_lane():
             texts += ["ab" * 150 + "e", "abcd" * 150 + "e", "ab" * 301 + "e", "ab" + "e", "abab" + "e"]
         for t in texts:
             assert rep.accepts(t.encode()) == o.accepts(t), (p, len(t))
+
+
+def test_stride2_program_keeps_the_language():
+    """The two-bytes-per-step table (pair columns + T2) against the oracle, line by line, incl. line ends on either
+    byte of a pair, empty lines, odd and even corpus lengths."""
+    import numpy as np
+    rng = random.Random(51)
+    pats = [EMAIL, U2, "a{1,300}", K1000, "abc", "a*", "(ab|cd)+e?", "[ab]+c[ab]*"]
+    for _ in range(25):
+        p = random_pattern(rng)
+        try:
+            OracleRegex(p)
+            if rr.RRegex(p).program(rr.ENGINE_DFA2) is not None:
+                pats.append(p)
+        except (OracleError, rr.RRegexError):
+            pass
+    for p in pats:
+        o = OracleRegex(p)
+        w = rr.RRegex(p).program(rr.ENGINE_DFA2)
+        assert w is not None, p
+        rep = Dfa2Replay(w)
+        for trial in range(6):
+            lines = [random_pattern_text(rng, p) for _ in range(rng.randint(0, 12))]
+            data = "\n".join(lines).encode()
+            if trial % 2:
+                data += b"\n"
+            if trial == 4:
+                data = b"\n\n" + data + b"\n\n\n"
+            want = list(o.match_lines(np.frombuffer(data, dtype=np.uint8))) if data else []
+            assert rep.match_lines(data) == want, (p[:30], data[:60])
+
+
+def random_pattern_text(rng, p):
+    alphabet = "abcxk01.d@:/e" if len(p) < 60 else "abcdefghijklmnopqrstuvwxyz0123456789.:/-?#=&_~%@ "
+    return "".join(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 2, 3, 5, 8, 13, 30])))
