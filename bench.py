@@ -46,13 +46,13 @@ def patterns():
     return {"U2": u2, "EMAIL": r"[A-Za-z0-9._]+@[A-Za-z0-9.]+", "A300": "a{1,300}", "K1000": k1000, "K1000C": ".*(" + k1000 + ").*"}
 
 
-def measured_traffic(workload, nbytes):
+def measured_traffic(workload, nbytes, engine_name):
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE in
     separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, the factor re-checked on
     our own access pattern with the pure-streaming newline-count kernel).  Only quoted for the exact
-    configuration that was profiled: profiles/r01_v5_final_url_8GiB_rocprofv3_summary.txt."""
-    if workload == "url" and nbytes == 8 << 30:
-        fetch_kb, write_kb = 4.32915e6, 190439.0
+    configuration that was profiled: profiles/r01_v6_stride2_url_8GiB_rocprofv3_summary.txt."""
+    if workload == "url" and nbytes == 8 << 30 and engine_name == "dfa-stride2-table":
+        fetch_kb, write_kb = 4.62854e6, 176545.0
         return int(fetch_kb * 1024 * 2 + write_kb * 1024)
     return None
 
@@ -217,7 +217,7 @@ def main():
                        "bytes_per_gpu": nbytes, "stripe_bytes": corpus.stripe, "lines_per_gpu": nlines, "accepted_rank0": accepted, "sharding": "by lines, no collective"},
             "per_gpu_GBs": round(nbytes * args.steps / elapsed / 1e9, 2),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, nbytes),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, nbytes, regex.engine_name),
                          "frac_of_achievable_6.29TBs": round(achieved / HBM_ACHIEVABLE_GBS, 4),
                          "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "algorithmic_bytes_per_launch": nbytes},
             "setup": {"generate_s": round(gen_s, 2), "index_ms": round(index_ms, 3)},

@@ -495,10 +495,10 @@ struct Dfa2 {
 __global__ __launch_bounds__(kThreads) void match_stripes2_kernel(Dfa2Device prog, const uint8_t *__restrict__ bytes, size_t nbytes,
                                                                    uint32_t stripe, const uint64_t *__restrict__ stripe_base,
                                                                    uint32_t *__restrict__ accept_bits) {
-    __shared__ __attribute__((aligned(16))) uint16_t p_lds[kDfa2PBytes / 2];     // 33,280 bytes: a multiple of 16
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // T2 first: its entries hold 16-bit LDS addresses.  Both arrays are static, so every base is a link-time constant.
+    __shared__ __attribute__((aligned(16))) struct { uint8_t t2[kDfa2TableBudget]; uint16_t p[kDfa2PBytes / 2]; } lds;
     Dfa2 eng;
-    eng.load(prog, p_lds, smem);
+    eng.load(prog, lds.p, lds.t2);
     __syncthreads();
 
     const size_t g = (size_t)blockIdx.x * kThreads + threadIdx.x;
@@ -941,11 +941,9 @@ int match_extents_wave_nfa(const WaveNfaDevice &p, const uint8_t *bytes, const u
 int match_stripes_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
                        size_t nstripes, uint32_t *accept, void *stream) {
     if (!nstripes) return 0;
-    const size_t lds = Dfa2::lds_bytes(p);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(match_stripes2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
+    if (Dfa2::lds_bytes(p) > kDfa2TableBudget) return (int)hipErrorInvalidValue;
     size_t blocks = (nstripes + kThreads - 1) / kThreads;
-    hipLaunchKernelGGL(match_stripes2_kernel, dim3((unsigned)blocks), dim3(kThreads), lds, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept);
+    hipLaunchKernelGGL(match_stripes2_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept);
     return (int)hipGetLastError();
 }
 int match_extents_nfa(const NfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim, uint8_t *accept,
