@@ -444,9 +444,6 @@ int rrx_match_host(const rrx_regex *re, int device, const void *bytes, size_t nb
         if (e == hipSuccess) e = hipStreamCreate(&st[i]);
     }
     if (e != hipSuccess) rc = hip_fail(e, "pipeline buffers");
-    // pin the caller's pages so that the copies are asynchronous DMA (best effort)
-    const bool pinned = !rc && nbuf == 2 && hipHostRegister(const_cast<uint8_t *>(host), nbytes, hipHostRegisterDefault) == hipSuccess;
-    if (!pinned) (void)hipGetLastError();
 
     // chunk boundaries: right after the last '\n' of each window (a window without any '\n' is taken whole: the
     // line continues, and since a line must be matched by one launch such inputs fall back to one big chunk)
@@ -463,13 +460,17 @@ int rrx_match_host(const rrx_regex *re, int device, const void *bytes, size_t nb
     }
     const size_t nchunks = cuts.size() - 1;
     size_t line_off = 0;
+    // The caller's pages are NOT pinned: on this platform the runtime's own staged copy from pageable memory runs at
+    // 49 GB/s (57 pinned), while pinning costs as much as the copy (hipHostRegister + hipHostUnregister: ~30 ms per
+    // GiB).  Measured on 4 GiB: 42 GB/s unpinned, 31 GB/s pinning everything first, 33 GB/s pinning 64-MiB windows on
+    // a helper thread ahead of the uploads.
     if (!rc) {
         e = hipMemcpyAsync(d_text[0], host, cuts[1] - cuts[0], hipMemcpyHostToDevice, st[0]);
         if (e != hipSuccess) rc = hip_fail(e, "chunk upload");
     }
     for (size_t i = 0; i < nchunks && !rc; i++) {
         const int cur = (int)(i & 1) % nbuf, nxt = (int)((i + 1) & 1) % nbuf;
-        if (i + 1 < nchunks) {                                             // next chunk's copy overlaps this chunk's work
+        if (i + 1 < nchunks) {                                             // next chunk's upload is queued before this chunk's work
             e = hipMemcpyAsync(d_text[nxt], host + cuts[i + 1], cuts[i + 2] - cuts[i + 1], hipMemcpyHostToDevice, st[nxt]);
             if (e != hipSuccess) { rc = hip_fail(e, "chunk upload"); break; }
         }
@@ -478,7 +479,6 @@ int rrx_match_host(const rrx_regex *re, int device, const void *bytes, size_t nb
         line_off += n;
     }
     for (int i = 0; i < nbuf; i++) if (st[i]) (void)hipStreamSynchronize(st[i]);
-    if (pinned) (void)hipHostUnregister(const_cast<uint8_t *>(host));
     for (int i = 0; i < 2; i++) {
         if (d_text[i]) (void)hipFree(d_text[i]);
         if (d_acc[i]) (void)hipFree(d_acc[i]);

@@ -323,7 +323,7 @@ def test_wave_cooperative_engine_on_large_automata():
 
 
 def test_match_host_pipeline_equals_resident_path():
-    """rrx_match_host on an input larger than its 256 MiB chunk: pinned, chunked, double-buffered upload must give
+    """rrx_match_host on an input larger than its 256 MiB chunk: the chunked, double-buffered upload must give
     exactly the accept vector of the device-resident path (and of the oracle on a sampled chunk)."""
     import synth
     n = (600 << 20) + 12345
