@@ -80,6 +80,12 @@ int rrx_bitmap_to_bytes(int device, const uint32_t *d_accept_bits, size_t nlines
 int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, const uint64_t *d_off, size_t nitems,
                       uint32_t trim, uint8_t *d_accept, void *stream);
 
+/* ONE device-resident string of any length (regex.h:156-159: operator++ consumes the whole string; '\n' and every
+ * other byte are ordinary, a NUL or a byte >= 0x80 rejects).  d_accept[0] = 1 iff accepted.  Strings of 32 KiB and
+ * more are split into chunks that are stepped in parallel from every table state (automata with <= 254 table
+ * states); synchronous with respect to `stream`.                                                                */
+int rrx_match_string(const rrx_regex *re, int device, const void *d_bytes, size_t nbytes, uint8_t *d_accept, void *stream);
+
 /* ---- host-buffer conveniences (PCIe inclusive; synchronous) ------------------------------------------ */
 /* bytes/accept are HOST pointers; *nlines receives the number of strings; at most cap results are written */
 int rrx_match_host(const rrx_regex *re, int device, const void *bytes, size_t nbytes, uint8_t *accept, size_t cap,

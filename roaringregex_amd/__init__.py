@@ -23,7 +23,7 @@ ABI_SYMBOLS = (
     "rrx_program_words",
     "rrx_corpus_create", "rrx_corpus_create_ex", "rrx_corpus_stripe_bytes", "rrx_corpus_num_lines", "rrx_corpus_num_bytes", "rrx_corpus_free", "rrx_corpus_bitmap_words",
     "rrx_match_corpus", "rrx_bitmap_to_bytes",
-    "rrx_match_extents", "rrx_match_host", "rrx_match_cstr",
+    "rrx_match_extents", "rrx_match_string", "rrx_match_host", "rrx_match_cstr",
 )
 
 
@@ -72,6 +72,7 @@ def _load():
         "rrx_match_corpus": (i32, [vp, vp, vp, vp]),
         "rrx_bitmap_to_bytes": (i32, [i32, vp, sz, vp, vp]),
         "rrx_match_extents": (i32, [vp, i32, vp, vp, sz, u32, vp, vp]),
+        "rrx_match_string": (i32, [vp, i32, vp, sz, vp, vp]),
         "rrx_match_host": (i32, [vp, i32, vp, sz, vp, sz, C.POINTER(sz)]),
         "rrx_match_cstr": (i32, [vp, i32, C.c_char_p, C.POINTER(i32), C.POINTER(sz)]),
     }
@@ -231,6 +232,16 @@ class RRegex:
                                         C.c_void_p(offsets.data_ptr()), n, trim, C.c_void_p(out.data_ptr() if n else 0),
                                         _stream_ptr(stream)))
         return out[:n]
+
+    def match_string(self, data, stream=None):
+        """ONE device-resident string of any length (regex.h:156-159); '\n' is an ordinary character.  -> bool"""
+        import torch
+        assert data.is_cuda and data.dtype == torch.uint8
+        out = torch.zeros(1, dtype=torch.uint8, device=data.device)
+        with torch.cuda.device(data.device.index):
+            _check(_L.rrx_match_string(self._h, data.device.index, C.c_void_p(data.data_ptr() if data.numel() else 0), data.numel(),
+                                       C.c_void_p(out.data_ptr()), _stream_ptr(stream)))
+        return bool(out.item())
 
     def match_host(self, data):
         """Host bytes in, numpy accept vector out (upload + index + match + download; synchronous)."""

@@ -202,6 +202,8 @@ struct rrx_corpus {
     bool has_high = false;          // some byte >= 0x80 occurs
 };
 
+static constexpr size_t kLongStringBytes = 32 * 1024;   // shorter single strings stay on one lane
+
 extern "C" {
 
 const char *rrx_last_error(void) { return g_err.c_str(); }
@@ -399,9 +401,44 @@ int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, cons
     return RRX_OK;
 }
 
-// Host buffer in, one byte per string out.  Large inputs are pipelined: the caller's buffer is pinned in place
-// (hipHostRegister), cut into line-aligned chunks, and the H2D copy of chunk i+1 runs on one stream while index +
-// match + download of chunk i run on the other (two device buffers).  PCIe inclusive; never the benchmarked rate.
+// One device-resident string of any length.  Long strings take the chunk-map path when the automaton has a small
+// table (every chunk stepped from every state, maps composed); the rest is one item of the extents kernel.
+int rrx_match_string(const rrx_regex *re, int device, const void *d_bytes, size_t nbytes, uint8_t *d_accept, void *stream) {
+    if (!re || (nbytes && !d_bytes) || !d_accept) return fail(RRX_ERR_ARG, "null argument");
+    const DeviceTables *t;
+    int rc = re->tables(device, &t);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(device));
+    const bool table_engine = re->engine != RRX_ENGINE_NFA && re->engine != RRX_ENGINE_NFA_WAVE;
+    if (table_engine && nbytes >= kLongStringBytes && t->dfa.nstates && t->dfa.nstates <= dev::kLongMaxStates) {
+        uint32_t chunk = 0;
+        const size_t need = dev::long_scratch_bytes(t->dfa.nstates, nbytes, &chunk);
+        void *scratch = nullptr;
+        hipError_t e = hipMalloc(&scratch, need);
+        if (e != hipSuccess) return hip_fail(e, "hipMalloc(chunk maps)");
+        int le = dev::match_long_dfa(t->dfa, static_cast<const uint8_t *>(d_bytes), nbytes, chunk, scratch, d_accept, stream);
+        e = hipStreamSynchronize(static_cast<hipStream_t>(stream));           // the maps are freed next
+        (void)hipFree(scratch);
+        if (le) return hip_fail((hipError_t)le, "match_long launch");
+        if (e != hipSuccess) return hip_fail(e, "match_long");
+        return RRX_OK;
+    }
+    uint64_t *d_off = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_off), 2 * sizeof(uint64_t));
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(extent)");
+    const uint64_t off[2] = {0, nbytes};
+    e = hipMemcpyAsync(d_off, off, sizeof off, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream));
+    if (e == hipSuccess) e = hipStreamSynchronize(static_cast<hipStream_t>(stream));     // `off` leaves scope
+    if (e != hipSuccess) rc = hip_fail(e, "extent upload");
+    if (!rc) rc = rrx_match_extents(re, device, d_bytes, d_off, 1, 0, d_accept, stream);
+    e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+    if (!rc && e != hipSuccess) rc = hip_fail(e, "match_string");
+    (void)hipFree(d_off);
+    return rc;
+}
+
+// Host buffer in, one byte per string out.  Large inputs are cut into line-aligned chunks; the upload of chunk i+1 is
+// queued before index + match + download of chunk i (two device buffers).  PCIe inclusive; never the benchmarked rate.
 static int match_host_chunk(const rrx_regex *re, int device, uint8_t *d_text, size_t len, hipStream_t st, uint32_t *d_bits,
                             uint8_t *d_acc, uint8_t *accept, size_t cap, size_t line_off, size_t *nlines_out) {
     rrx_corpus *c = nullptr;
@@ -495,18 +532,15 @@ int rrx_match_cstr(const rrx_regex *re, int device, const char *text, int *accep
     if (len) *len = n;
     HIP_TRY(hipSetDevice(device));
     uint8_t *d = nullptr;
-    const size_t off_at = (n + 15) & ~(size_t)15;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d), off_at + 32);
+    const size_t acc_at = (n + 15) & ~(size_t)15;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d), acc_at + 16);
     if (e != hipSuccess) return hip_fail(e, "hipMalloc(text)");
-    uint64_t off[2] = {0, n};
     int rc = RRX_OK;
     if (n) e = hipMemcpy(d, text, n, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(d + off_at, off, sizeof off, hipMemcpyHostToDevice);
     if (e != hipSuccess) rc = hip_fail(e, "text upload");
-    uint8_t *d_acc = d + off_at + 16;
-    if (!rc) rc = rrx_match_extents(re, device, d, reinterpret_cast<const uint64_t *>(d + off_at), 1, 0, d_acc, nullptr);
+    if (!rc) rc = rrx_match_string(re, device, d, n, d + acc_at, nullptr);
     uint8_t a = 0;
-    if (!rc) { e = hipMemcpy(&a, d_acc, 1, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hip_fail(e, "accept readback"); }
+    if (!rc) { e = hipMemcpy(&a, d + acc_at, 1, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hip_fail(e, "accept readback"); }
     (void)hipFree(d);
     *accepted = a;
     return rc;

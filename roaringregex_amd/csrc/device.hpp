@@ -113,6 +113,14 @@ int match_extents_wave_nfa(const WaveNfaDevice &p, const uint8_t *bytes, const u
                            uint8_t *accept, void *stream);
 
 // items i = bytes[off[i] .. off[i+1] - trim) ; trim = 1 drops a trailing delimiter byte per item
+// One long string (regex.h:156-159 consumes it byte by byte): the string is cut into chunks, every chunk is stepped
+// from EVERY table state at once (lane = (chunk, start state); the lanes of a chunk read the same text), which yields
+// one state -> state map per chunk; maps are then composed in groups until one is left.  `scratch` holds the maps.
+constexpr uint32_t kLongMaxStates = 254;         // row offsets state * 129 stay 16-bit
+constexpr uint32_t kLongGroup = 128;             // maps composed per workgroup and level
+size_t long_scratch_bytes(uint32_t nstates, size_t nbytes, uint32_t *chunk);
+int match_long_dfa(const DfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t chunk, void *scratch, uint8_t *accept,
+                   void *stream);
 int match_extents_nfa(const NfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim,
                       uint8_t *accept, void *stream);
 int match_extents_dfa(const DfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim,

@@ -859,6 +859,57 @@ int launch_stripes(const Program &p, size_t table_bytes, const uint8_t *bytes, s
     return (int)hipGetLastError();
 }
 
+// ============================================================================================ one long string
+// Chunk maps.  LDS: the plain DFA widened to one u16 entry per (state, byte value 0..127 | >= 0x80), entry = row
+// offset of the next state (state * 129), so a step is one clamp, one add and one ds_read_u16.
+constexpr int kLongThreads = 256;
+__global__ __launch_bounds__(kLongThreads) void long_maps_kernel(DfaDevice p, const uint8_t *__restrict__ bytes, size_t nbytes, uint32_t chunk,
+                                                                 uint32_t nchunks, uint16_t *__restrict__ maps) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t *wide = reinterpret_cast<uint16_t *>(smem);
+    const uint32_t D = p.nstates;
+    for (uint32_t i = threadIdx.x; i < D * kWideColumns; i += kLongThreads) {
+        const uint32_t s = i / kWideColumns, c = i % kWideColumns;
+        wide[i] = (uint16_t)(p.next[s * p.ncls + p.cls[c]] * kWideColumns);     // column 128 stands for every byte >= 0x80
+    }
+    __syncthreads();
+    const uint32_t per_block = kLongThreads / D, ci = threadIdx.x / D, s0 = threadIdx.x % D;
+    const size_t k = (size_t)blockIdx.x * per_block + ci;
+    if (ci >= per_block || k >= nchunks) return;
+    const size_t a = k * (size_t)chunk, b = a + chunk < nbytes ? a + chunk : nbytes;
+    uint32_t row = s0 * kWideColumns;
+    size_t pos = a;
+    if ((reinterpret_cast<uintptr_t>(bytes) & 15) == 0) {                       // chunk starts are multiples of 16
+        for (; pos + 16 <= b; pos += 16) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(bytes + pos);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t c = (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                row = wide[row + (c < 128 ? c : 128)];
+            }
+        }
+    }
+    for (; pos < b; pos++) {
+        const uint32_t c = bytes[pos];
+        row = wide[row + (c < 128 ? c : 128)];
+    }
+    maps[k * D + s0] = (uint16_t)(row / kWideColumns);
+}
+// out[g] = in[g*group + group-1] o ... o in[g*group]   (one lane per start state; dependent L2 reads)
+__global__ __launch_bounds__(kLongThreads) void long_compose_kernel(const uint16_t *__restrict__ in, uint32_t nin, uint32_t D, uint32_t group,
+                                                                    uint16_t *__restrict__ out) {
+    const uint32_t j = threadIdx.x;
+    if (j >= D) return;
+    const size_t lo = (size_t)blockIdx.x * group, hi = lo + group < nin ? lo + group : nin;
+    uint32_t s = j;
+    for (size_t k = lo; k < hi; k++) s = in[k * D + s];
+    out[(size_t)blockIdx.x * D + j] = (uint16_t)s;
+}
+__global__ void long_finish_kernel(const uint16_t *__restrict__ map, DfaDevice p, uint8_t *__restrict__ accept) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) accept[0] = p.acc[map[p.start]];
+}
+
 template <class Engine, class Program>
 int launch_extents(const Program &p, size_t table_bytes, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim,
                    uint8_t *accept, void *stream) {
@@ -951,6 +1002,39 @@ int match_extents_nfa(const NfaDevice &p, const uint8_t *bytes, const uint64_t *
 #define CALL(WW) launch_extents<PlainNfaEngine<WW>, NfaDevice>(p, PlainNfaEngine<WW>::lds_bytes(p), bytes, off, nitems, trim, accept, stream)
     RRX_NFA_DISPATCH(CALL)
 #undef CALL
+}
+static uint32_t long_chunk(size_t nbytes) {
+    uint32_t chunk = 1024;                                     // at most 65536 chunks, of 1 KiB or more
+    while (((nbytes + chunk - 1) / chunk) > 65536) chunk <<= 1;
+    return chunk;
+}
+size_t long_scratch_bytes(uint32_t nstates, size_t nbytes, uint32_t *chunk) {
+    *chunk = long_chunk(nbytes);
+    const size_t k0 = (nbytes + *chunk - 1) / *chunk, k1 = (k0 + kLongGroup - 1) / kLongGroup;
+    return (k0 + k1 + 2) * nstates * sizeof(uint16_t);         // level 0, then the levels ping-pong between two areas
+}
+int match_long_dfa(const DfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t chunk, void *scratch, uint8_t *accept,
+                   void *stream) {
+    const uint32_t D = p.nstates;
+    if (!D || D > kLongMaxStates || !nbytes) return (int)hipErrorInvalidValue;
+    const size_t lds = (size_t)D * kWideColumns * sizeof(uint16_t);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(long_maps_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    uint32_t n = (uint32_t)((nbytes + chunk - 1) / chunk);
+    uint16_t *cur = static_cast<uint16_t *>(scratch), *other = cur + (size_t)n * D;
+    const uint32_t per_block = kLongThreads / D;
+    hipLaunchKernelGGL(long_maps_kernel, dim3((n + per_block - 1) / per_block), dim3(kLongThreads), lds, (hipStream_t)stream, p, bytes, nbytes,
+                       chunk, n, cur);
+    uint16_t *area[2] = {other, cur};                          // level 1 writes behind level 0, level 2 over level 0, ...
+    for (int lvl = 0; n > 1; lvl++) {
+        const uint32_t m = (n + kLongGroup - 1) / kLongGroup;
+        uint16_t *dst = area[lvl & 1];
+        hipLaunchKernelGGL(long_compose_kernel, dim3(m), dim3(kLongThreads), 0, (hipStream_t)stream, cur, n, D, kLongGroup, dst);
+        cur = dst;
+        n = m;
+    }
+    hipLaunchKernelGGL(long_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cur, p, accept);
+    return (int)hipGetLastError();
 }
 int match_extents_dfa(const DfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim, uint8_t *accept,
                       void *stream) {

@@ -360,3 +360,44 @@ def test_extents_with_unaligned_items_of_many_lengths():
     for r in engines_for(p, small=True):
         got = r.match_extents(data, offs).cpu().numpy()
         assert list(got) == want, r.engine_name
+
+
+# ------------------------------------------------------------------------------------------ one long string
+def test_one_long_string_is_stepped_in_parallel_chunks():
+    """regex.h:156-159 consumes ONE string; rrx_match_string cuts a long one into chunks, steps every chunk from every
+    table state and composes the chunk maps.  Lengths straddle the 32 KiB threshold, the chunk size and one, two and
+    three composition levels; '\n' is an ordinary byte; a byte >= 0x80 rejects."""
+    rng = np.random.default_rng(21)
+    ab = np.frombuffer(b"ab", dtype=np.uint8)
+    cases = []
+    for n in (32 * 1024 - 1, 32 * 1024, 32 * 1024 + 1, 100_003, (1 << 20) + 17, 5 * (1 << 20) + 1023, 20 * (1 << 20) + 5):
+        body = ab[rng.integers(0, 2, size=n)]
+        for tail in (b"abb", b"aba"):
+            t = body.copy()
+            t[-3:] = np.frombuffer(tail, dtype=np.uint8)
+            cases.append(("(a|b)*abb", t))
+    text = np.frombuffer(b"the quick brown fox\n", dtype=np.uint8)
+    big = np.tile(text, 60000)                                  # 1.2 MB with '\n' inside
+    hit = big.copy(); hit[777_777:777_780] = np.frombuffer(b"abc", dtype=np.uint8)
+    cases += [(".*abc.*", big), (".*abc.*", hit), ("abc", hit), ("(the quick brown fox.)*", big), ("(the quick brown fox.)*", big[:-1])]
+    high = hit.copy(); high[999_999] = 0xC3
+    cases.append((".*abc.*", high))
+    url = np.frombuffer(b"https://www.example.com/" + b"a/b-c_d.e" * 30000 + b"?q=1", dtype=np.uint8)
+    cases += [(U2, url), (U2, url[:-4]), (U2, np.concatenate([url, np.frombuffer(b" x", dtype=np.uint8)]))]
+    oracles = {}
+    for pattern, t in cases:
+        o = oracles.setdefault(pattern, OracleRegex(pattern))
+        want = o.accepts(t.tobytes())
+        dev = torch.from_numpy(np.array(t, copy=True)).cuda()
+        for e in (rr.ENGINE_AUTO, rr.ENGINE_DFA, rr.ENGINE_NFA):
+            if e == rr.ENGINE_NFA and len(t) > (1 << 20) + 17:
+                continue                                        # one sequential lane: keep it to the short cases
+            r = rr.RRegex(pattern, e)
+            assert r.match_string(dev) == want, (pattern[:30], len(t), r.engine_name)
+    # the iterator facade takes the same path for a long host string
+    r = rr.RRegex("(a|b)*abb")
+    s = (b"ab" * 100000) + b"abb"
+    it = r.get_acceptance_iter(s).advance()
+    m = it.value()
+    assert m is not None and (m.start, m.end) == (0, len(s))
+    assert r.get_acceptance_iter(s + b"a").advance().value() is None
