@@ -90,7 +90,7 @@ struct Dfa2Device {
 };
 constexpr uint32_t kDfa2PStride = 130;                // u16 entries per P row
 constexpr uint32_t kDfa2PBytes = 128 * kDfa2PStride * 2;
-constexpr uint32_t kDfa2TableBudget = 46 * 1024;     // T2 + P (32.5 KiB) = 78.5 KiB: two 1024-lane workgroups per 160-KiB CU
+constexpr uint32_t kDfa2TableBudget = 30 * 1024;     // T2 + P (32.5 KiB) + 16 KiB result window = 78.5 KiB: two 1024-lane workgroups per 160-KiB CU
 
 int match_stripes_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
                        size_t nstripes, uint32_t *accept_bits, void *stream);

@@ -293,24 +293,64 @@ struct PlainDfaEngine {
     __device__ __forceinline__ void step(State &st, uint32_t c) const { st.s = next[st.s * ncls + cls[c]]; }
 };
 
+// Text is read once: a streaming (non-temporal) load keeps it from displacing the accept bitmap's lines in L2.
+#ifndef RRX_TEXT_NT
+#define RRX_TEXT_NT 0
+#endif
+__device__ __forceinline__ uint4 load_text(const uint4 *p) {
+#if RRX_TEXT_NT
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+#else
+    return *p;
+#endif
+}
+
 // ============================================================================================ batch kernel
 // Line verdicts of one lane.  `bits` = sentinel 1 followed by one verdict bit per line finished since the
 // last flush (oldest highest).  flush() appends them, oldest first, to the lane's current output word at bit
 // position `fill` and ORs every completed word into the accept bitmap (bit i of the bitmap = line i).
 // The first result of a lane that started inside somebody else's line belongs to that somebody (who reports
 // it when it follows the line past its own stripe): its bit is skipped but its index is consumed.
-struct Results {
+// STAGED: completed words are ORed into a per-workgroup LDS window of the bitmap (`stage`, kStageWords words from the
+// word that holds the workgroup's first line) and written out by the whole workgroup at the end, 256 contiguous bytes
+// per wave instruction.  Scattered 4-byte global atomics leave L2 as partial-line DRAM writes: 5.6 M of them per
+// launch on the URL config cost 4-6 % of the kernel (probes: atomics confined to 16 KiB of L2, no memory operation).
+// Words beyond the window (a workgroup whose lines average < 32 bytes) still go to memory directly.
+constexpr uint32_t kStageWords = 4096;
+template <bool STAGED>
+struct ResultsT {
     uint32_t bits = 1;
     uint32_t outw = 0;
     uint32_t fill;
     uint32_t seen = 0;
-    uint64_t word;
+    uint64_t word;                         // STAGED: relative to the first word of the window
     bool drop_first;
     bool writer = true;                    // wave-cooperative kernels: every lane mirrors the bookkeeping, one writes
-    uint32_t *__restrict__ out;
+    uint32_t *__restrict__ out;            // STAGED: already advanced to the first word of the window
+    uint32_t *stage = nullptr;
 
     __device__ __forceinline__ void begin(uint64_t first_line, bool drop, uint32_t *bitmap) {
         word = first_line >> 5; fill = (uint32_t)first_line & 31u; drop_first = drop; out = bitmap;
+    }
+    __device__ __forceinline__ void begin_staged(uint64_t first_line, uint64_t window_word, bool drop, uint32_t *bitmap, uint32_t *lds) {
+        word = (first_line >> 5) - window_word; fill = (uint32_t)first_line & 31u; drop_first = drop;
+        out = bitmap + window_word; stage = lds;
+    }
+    __device__ __forceinline__ void emit() {
+        if (!outw || !writer) return;
+        if (STAGED && word < kStageWords) atomicOr(&stage[(uint32_t)word], outw);
+        else
+#if defined(RRX_PROBE_FLUSH_STORE)      /* measurement only: plain store instead of the atomic (wrong at shared words) */
+            out[word] = outw;
+#elif defined(RRX_PROBE_FLUSH_LOCAL)    /* measurement only: the atomics all land in 16 KiB that stay in L2 */
+            atomicOr(&out[word & 4095], outw);
+#elif defined(RRX_PROBE_FLUSH_NOMEM)    /* measurement only: the flush arithmetic without the memory operation */
+            asm volatile("" :: "v"(outw), "v"(word));
+#else
+            atomicOr(&out[word], outw);
+#endif
     }
     __device__ __forceinline__ void push(uint32_t nl, uint32_t acc) { bits = (bits << nl) | acc; }
     __device__ __forceinline__ void flush() {
@@ -324,7 +364,7 @@ struct Results {
             outw |= rev << fill;
             uint32_t nf = fill + (uint32_t)n;
             if (nf >= 32u) {                                 // then fill >= 1
-                if (outw && writer) atomicOr(&out[word], outw);
+                emit();
                 word++;
                 outw = rev >> (32u - fill);
                 nf -= 32u;
@@ -336,10 +376,11 @@ struct Results {
     }
     __device__ __forceinline__ void finish() {
         flush();
-        if (outw && writer) atomicOr(&out[word], outw);
+        emit();
         outw = 0;
     }
 };
+typedef ResultsT<false> Results;
 
 template <class Engine, class Program>
 __global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, const uint8_t *__restrict__ bytes, size_t nbytes,
@@ -371,7 +412,7 @@ __global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, c
     uint4 buf[kSlots];
     if (rounds > 0) {
 #pragma unroll
-        for (int i = 0; i < kSlots; i++) buf[i] = src[i];
+        for (int i = 0; i < kSlots; i++) buf[i] = load_text(src + i);
     }
     for (int r = 0; r < rounds; r++) {
 #pragma unroll
@@ -392,7 +433,7 @@ __global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, c
         if ((r & 3) == 3) res.flush();
         if (r + 1 < rounds) {
 #pragma unroll
-            for (int i = 0; i < kSlots; i++) buf[i] = src[(r + 1) * kSlots + i];
+            for (int i = 0; i < kSlots; i++) buf[i] = load_text(src + (r + 1) * kSlots + i);
         }
     }
     pos += (size_t)rounds * kRound;
@@ -476,15 +517,22 @@ struct Dfa2 {
         asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(ia) : "v"(ta), "v"(w2));
         asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(tb) : "v"(w2), "v"(stride));
         asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(ib) : "v"(tb), "v"(w2));
-        const uint32_t ca = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(P) + ia);
-        const uint32_t cb = *reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(P) + ib);
+#ifdef RRX_PROBE_NO_LOOKUP      /* measurement only: same feed, VALU work and result path, no LDS gathers (results are wrong) */
+#define RRX_LDS_U16(x) ((x) & 0x3cu)
+#define RRX_LDS_U32(x) ((x) & 0x0001ffffu)
+#else
+#define RRX_LDS_U16(x) (*reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(P) + (x)))
+#define RRX_LDS_U32(x) (*reinterpret_cast<lds_u32_ptr>(x))
+#endif
+        const uint32_t ca = RRX_LDS_U16(ia);
+        const uint32_t cb = RRX_LDS_U16(ib);
         uint32_t addr;
         asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(addr) : "v"(st.e), "v"(ca));
-        st.e = *reinterpret_cast<lds_u32_ptr>(addr);
+        st.e = RRX_LDS_U32(addr);
         asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(bits) : "v"(st.e), "v"(bits));
         asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(bits) : "v"(st.e), "v"(bits));
         asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(addr) : "v"(st.e), "v"(cb));
-        st.e = *reinterpret_cast<lds_u32_ptr>(addr);
+        st.e = RRX_LDS_U32(addr);
         asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(bits) : "v"(st.e), "v"(bits));
         asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(bits) : "v"(st.e), "v"(bits));
     }
@@ -495,21 +543,28 @@ struct Dfa2 {
 __global__ __launch_bounds__(kThreads) void match_stripes2_kernel(Dfa2Device prog, const uint8_t *__restrict__ bytes, size_t nbytes,
                                                                    uint32_t stripe, const uint64_t *__restrict__ stripe_base,
                                                                    uint32_t *__restrict__ accept_bits) {
-    // T2 first: its entries hold 16-bit LDS addresses.  Both arrays are static, so every base is a link-time constant.
-    __shared__ __attribute__((aligned(16))) struct { uint8_t t2[kDfa2TableBudget]; uint16_t p[kDfa2PBytes / 2]; } lds;
+    // T2 first: its entries hold 16-bit LDS addresses.  All arrays are static, so every base is a link-time constant.
+    __shared__ __attribute__((aligned(16))) struct {
+        uint8_t t2[kDfa2TableBudget];
+        uint16_t p[kDfa2PBytes / 2];
+        uint32_t stage[kStageWords];
+    } lds;
     Dfa2 eng;
     eng.load(prog, lds.p, lds.t2);
+    for (uint32_t i = threadIdx.x; i < kStageWords; i += kThreads) lds.stage[i] = 0;
     __syncthreads();
 
-    const size_t g = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    const size_t g0 = (size_t)blockIdx.x * kThreads;
+    const uint64_t window_word = stripe_base[g0] >> 5;               // the workgroup's first stripe exists: uniform load
+    const size_t g = g0 + threadIdx.x;
     const size_t start = g * (size_t)stripe;
-    if (start >= nbytes) return;
+    if (start < nbytes) {                                            // (no early return: the write-out below is collective)
     const size_t stripe_end = start + stripe;
     const size_t my_end = stripe_end < nbytes ? stripe_end : nbytes;
     const bool fresh = start == 0 || bytes[start - 1] == '\n';
     Dfa2::State st = fresh ? eng.fresh() : eng.skipping();
-    Results res;
-    res.begin(stripe_base[g], !fresh, accept_bits);
+    ResultsT<true> res;
+    res.begin_staged(stripe_base[g], window_word, !fresh, accept_bits, lds.stage);
 
     size_t pos = start;
     const uint4 *src = reinterpret_cast<const uint4 *>(bytes + start);
@@ -518,7 +573,7 @@ __global__ __launch_bounds__(kThreads) void match_stripes2_kernel(Dfa2Device pro
     uint4 buf[kSlots];
     if (rounds > 0) {
 #pragma unroll
-        for (int i = 0; i < kSlots; i++) buf[i] = src[i];
+        for (int i = 0; i < kSlots; i++) buf[i] = load_text(src + i);
     }
     for (int r = 0; r < rounds; r++) {
 #pragma unroll
@@ -532,7 +587,7 @@ __global__ __launch_bounds__(kThreads) void match_stripes2_kernel(Dfa2Device pro
         if ((r & 3) == 3) res.flush();
         if (r + 1 < rounds) {
 #pragma unroll
-            for (int i = 0; i < kSlots; i++) buf[i] = src[(r + 1) * kSlots + i];
+            for (int i = 0; i < kSlots; i++) buf[i] = load_text(src + (r + 1) * kSlots + i);
         }
     }
     pos += (size_t)rounds * kRound;
@@ -575,6 +630,14 @@ __global__ __launch_bounds__(kThreads) void match_stripes2_kernel(Dfa2Device pro
         res.push(1, lines == 2 ? verdicts >> 1 : verdicts);     // only the first line end of the pair is mine
     }
     res.finish();
+    }
+    // ---- write the window out: consecutive lanes, consecutive words (the atomics merge into whole lines in L2;
+    // the first and the last word of the window are shared with the neighbouring workgroups)
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kStageWords; i += kThreads) {
+        const uint32_t v = lds.stage[i];
+        if (v) atomicOr(&accept_bits[window_word + i], v);
+    }
 }
 
 // ============================================================================================ wave-cooperative NFA
