@@ -38,6 +38,7 @@ namespace {
 // ---- wide / classed table DFA: '\n' handling folded into the table -------------------------------
 template <bool WIDE, bool CLAMP>
 struct LineDfaEngine {
+    static constexpr bool kStaged = true;      // results go through the workgroup's LDS window (ResultsT<true>)
     // Table entry: bits 0..15 = byte offset of the next row, byte 2 = 1 iff the consumed byte was '\n',
     // byte 3 = verdict of the line it ended.  (16-bit entries read with ds_read_u16 measured 3-4 % slower.)
     struct State { uint32_t e; };
@@ -130,6 +131,7 @@ struct LineDfaEngine {
 
 // ---- table DFA whose table stays in global memory (L2-resident): any automaton up to 65535 interned sets ----
 struct LineDfaGlobalEngine {
+    static constexpr bool kStaged = true;
     struct State { uint32_t e; };          // low 24 bits = index of the current row's first entry
     const uint32_t *__restrict__ tab;      // HBM / L2
     const uint8_t *cls;                    // LDS [256]
@@ -219,6 +221,7 @@ struct NfaCore {
 
 template <int W>
 struct LineNfaEngine : NfaCore<W> {
+    static constexpr bool kStaged = false;     // measured 10 % slower with the window (register pressure)
     using State = typename NfaCore<W>::State;
     __device__ __forceinline__ State fresh() const {
         State st;
@@ -385,21 +388,28 @@ typedef ResultsT<false> Results;
 template <class Engine, class Program>
 __global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, const uint8_t *__restrict__ bytes, size_t nbytes,
                                                                   uint32_t stripe, const uint64_t *__restrict__ stripe_base,
-                                                                  uint32_t *__restrict__ accept_bits) {
+                                                                  uint32_t *__restrict__ accept_bits, uint32_t stage_off) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // result window of the workgroup (ResultsT<true>), behind the tables: their entries hold 16-bit LDS addresses
+    uint32_t *stage = reinterpret_cast<uint32_t *>(smem + stage_off);
     Engine eng;
     eng.load(prog, smem);
+    if (Engine::kStaged)
+        for (uint32_t i = threadIdx.x; i < kStageWords; i += kThreads) stage[i] = 0;
     __syncthreads();
 
-    const size_t g = (size_t)blockIdx.x * kThreads + threadIdx.x;
+    const size_t g0 = (size_t)blockIdx.x * kThreads;
+    const uint64_t window_word = stripe_base[g0] >> 5;               // the workgroup's first stripe exists: uniform load
+    const size_t g = g0 + threadIdx.x;
     const size_t start = g * (size_t)stripe;
-    if (start >= nbytes) return;
+    if (start < nbytes) {                                            // (no early return: the write-out below is collective)
     const size_t stripe_end = start + stripe;
     const size_t my_end = stripe_end < nbytes ? stripe_end : nbytes;
     const bool fresh = start == 0 || bytes[start - 1] == '\n';
     typename Engine::State st = fresh ? eng.fresh() : eng.skipping();
-    Results res;
-    res.begin(stripe_base[g], !fresh, accept_bits);
+    ResultsT<Engine::kStaged> res;
+    if (Engine::kStaged) res.begin_staged(stripe_base[g], window_word, !fresh, accept_bits, stage);
+    else res.begin(stripe_base[g], !fresh, accept_bits);
 
     // ---- main phase: whole 128-byte rounds of my stripe.  The 8 loads of a line are issued as ONE burst after the
     // previous line has been consumed (they merge on one L2 request; other waves of the SIMD cover the fetch).
@@ -466,6 +476,14 @@ __global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, c
         res.push(nl, acc);
     }
     res.finish();
+    }
+    if (Engine::kStaged) {
+        __syncthreads();                             // write the window out: consecutive lanes, consecutive words
+        for (uint32_t i = threadIdx.x; i < kStageWords; i += kThreads) {
+            const uint32_t v = stage[i];
+            if (v) atomicOr(&accept_bits[window_word + i], v);
+        }
+    }
 }
 
 // ============================================================================================ stride-2 table kernel
@@ -915,10 +933,12 @@ int launch_stripes(const Program &p, size_t table_bytes, const uint8_t *bytes, s
                    const uint64_t *stripe_base, size_t nstripes, uint32_t *accept, void *stream) {
     if (!nstripes) return 0;
     auto k = match_stripes_kernel<Engine, Program>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)table_bytes);
+    const uint32_t stage_off = (uint32_t)((table_bytes + 15) & ~(size_t)15);
+    const size_t lds = Engine::kStaged ? stage_off + kStageWords * sizeof(uint32_t) : table_bytes;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     size_t blocks = (nstripes + kThreads - 1) / kThreads;
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), table_bytes, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept);
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept, stage_off);
     return (int)hipGetLastError();
 }
 
