@@ -50,9 +50,9 @@ def measured_traffic(workload, nbytes, engine_name):
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE in
     separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, the factor re-checked on
     our own access pattern with the pure-streaming newline-count kernel).  Only quoted for the exact
-    configuration that was profiled: profiles/r01_v6_stride2_url_8GiB_rocprofv3_summary.txt."""
+    configuration that was profiled: profiles/r01_v7_staged_url_8GiB_rocprofv3_summary.txt."""
     if workload == "url" and nbytes == 8 << 30 and engine_name == "dfa-stride2-table":
-        fetch_kb, write_kb = 4.62854e6, 176545.0
+        fetch_kb, write_kb = 4.58851e6, 24370.2
         return int(fetch_kb * 1024 * 2 + write_kb * 1024)
     return None
 
@@ -111,8 +111,8 @@ def cpu_baseline(pattern, host, target_seconds=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="url", choices=sorted(WORKLOADS))
     ap.add_argument("--bytes", type=int, default=0, help="bytes per GPU (default: the BASELINE size)")
     ap.add_argument("--engine", default="auto", choices=["auto", "nfa", "dfa", "dfa2"])
