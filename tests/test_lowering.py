@@ -204,3 +204,35 @@ def test_stride2_program_keeps_the_language():
 def random_pattern_text(rng, p):
     alphabet = "abcxk01.d@:/e" if len(p) < 60 else "abcdefghijklmnopqrstuvwxyz0123456789.:/-?#=&_~%@ "
     return "".join(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 2, 3, 5, 8, 13, 30])))
+
+
+def test_host_pipeline_is_clean_under_asan_and_ubsan(tmp_path):
+    """Sanitizers run on the CPU build only: the host compile pipeline (front end + every lowering) is plain C++, so
+    it is built here with g++ -fsanitize=address,undefined and driven with the known answers, the big configs, broken
+    patterns and random patterns.  Any report aborts the driver (-fno-sanitize-recover)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "roaringregex_amd", "csrc")
+    exe = str(tmp_path / "host_pipeline_asan")
+    subprocess.check_call(["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I", csrc,
+                           os.path.join(root, "tests", "cpp", "host_pipeline_driver.cpp"), os.path.join(csrc, "frontend.cpp"),
+                           os.path.join(csrc, "lower.cpp"), "-o", exe])
+    rng = random.Random(2024)
+    pats = [k["pattern"] for k in KAT["kat"]] + [b["pattern"] for b in KAT["big_states"]]
+    pats += [EMAIL, U2, "a{1,300}", "(a|b)*a(a|b){12}", "(a|b)*a(a|b){40}", K1000_CONTAINS]
+    pats += ["(", ")", "a)", "(a", "[", "[a", "a{", "a{2", "a{2,", "a{,}", "a{3,2}", "*", "+a", "a||b", "\\", "a\\", "[]", "[^]", "a{0}", "a{0,0}", "()", "(|)", ""]
+    pats += [random_pattern(rng) for _ in range(150)]
+    pats = [p for p in pats if "\n" not in p]
+    out = subprocess.run([exe], input=("\n".join(pats) + "\n").encode("latin-1"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode("latin-1")[-3000:]
+    lines = out.stdout.decode("latin-1").splitlines()
+    assert lines[-1].startswith("done %d " % len(pats)), lines[-1]
+    # the sanitized build must agree with the shipped library on what compiles
+    for p, line in zip(pats, lines):
+        try:
+            rr.RRegex(p)
+            ok = True
+        except rr.RRegexError as e:
+            ok = "too large" in str(e)               # compiled, but no device engine admits it
+        assert ok == (" ok " in line), (p[:60], line)
