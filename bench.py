@@ -119,6 +119,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stripe", type=int, default=0, help="bytes per GPU lane (0 = chosen from the corpus size)")
     ap.add_argument("--pcie", action="store_true", help="also time the host-buffer entry (upload + index + match + download)")
+    ap.add_argument("--search", action="store_true", help="also time rrx_search_corpus (match offsets per line) on the same corpus")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -228,6 +229,15 @@ def main():
             t0 = time.perf_counter()
             regex.match_host(sample)
             res["pcie_inclusive_GBs"] = round(len(sample) / (time.perf_counter() - t0) / 1e9, 3)
+        if args.search:
+            s, e = regex.search_corpus(corpus)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                s, e = regex.search_corpus(corpus)
+            torch.cuda.synchronize()
+            res["search"] = {"GBs": round(3 * nbytes / (time.perf_counter() - t0) / 1e9, 2), "lines_with_a_match": int((e >= 0).sum().item()),
+                             "mean_match_len": round(float((e - s)[e >= 0].double().mean().item()), 2) if int((e >= 0).sum().item()) else 0.0}
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(pattern, host)
         print(json.dumps(res), flush=True)

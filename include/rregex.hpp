@@ -127,6 +127,12 @@ public:
         auto *f = static_cast<DeviceIterFactory *>(iter_factory.get());
         if (rrx_match_corpus(f->handle(), corpus, d_accept_bits, stream) != RRX_OK) throw std::runtime_error(rrx_last_error());
     }
+    // search: per string the accepted substring [d_start[i], d_end[i]) with the smallest end, then the smallest start
+    // (offsets relative to the string; 0xFFFFFFFF = none).  The reference's README promises this, its code has not got it.
+    void search_corpus(const rrx_corpus *corpus, uint32_t *d_start, uint32_t *d_end, void *stream = nullptr) {
+        auto *f = static_cast<DeviceIterFactory *>(iter_factory.get());
+        if (rrx_search_corpus(f->handle(), corpus, d_start, d_end, stream) != RRX_OK) throw std::runtime_error(rrx_last_error());
+    }
 };
 
 }  // namespace Regex

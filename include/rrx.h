@@ -53,7 +53,10 @@ uint32_t    rrx_byte_classes(const rrx_regex *re);
 uint32_t    rrx_words_per_set(const rrx_regex *re); /* 32-bit words of the register-resident state set (NFA) */
 int         rrx_accepts_empty(const rrx_regex *re); /* Processor::operator*() on the initial set, NFA.cc:103-107 */
 /* Serialised device program as 32-bit words (layout: DESIGN.md "Device programs"); returns the word count
- * (call with cap = 0 to size the buffer).  kind = RRX_ENGINE_NFA / RRX_ENGINE_DFA; 0 if that form was not built. */
+ * (call with cap = 0 to size the buffer).  kind = RRX_ENGINE_NFA / _DFA / _NFA_WAVE / _DFA2, or one of the two
+ * search tables below (DFA layout); 0 if that form was not built.                                            */
+#define RRX_PROGRAM_SEARCH_FWD 6   /* "any bytes, then the pattern": accepting where a match ends              */
+#define RRX_PROGRAM_SEARCH_REV 7   /* the pattern right to left: accepting where a match starts                */
 size_t rrx_program_words(const rrx_regex *re, int kind, uint32_t *out, size_t cap);
 
 /* ---- batch of strings: the replacement for calling get_acceptance_iter(line)++ per string ------------ *
@@ -75,6 +78,13 @@ size_t rrx_corpus_bitmap_words(const rrx_corpus *c);   /* 32-bit words of the ac
 int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accept_bits, void *stream);
 /* One byte per string (0/1) from the bitmap; d_accept holds nlines bytes, 16-byte aligned.                  */
 int rrx_bitmap_to_bytes(int device, const uint32_t *d_accept_bits, size_t nlines, uint8_t *d_accept, void *stream);
+
+/* Search (the reference's README promises match iterators, its code has acceptance only: SURVEY.md 8(f).1).  For
+ * string i of the corpus: the substring [d_start[i], d_end[i]) (offsets relative to the start of the string) that the
+ * pattern accepts as a whole string (regex.h:156-162) with the smallest end, and among those the smallest start;
+ * 0xFFFFFFFF in both when no substring is accepted.  Bytes the pattern cannot match (including NUL and >= 0x80) are
+ * ordinary text here.  RRX_ERR_UNSUPPORTED when the two search tables do not fit the device.                     */
+int rrx_search_corpus(const rrx_regex *re, const rrx_corpus *corpus, uint32_t *d_start, uint32_t *d_end, void *stream);
 
 /* explicit extents: item i = d_bytes[d_off[i] .. d_off[i+1] - trim); '\n' is an ordinary character here */
 int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, const uint64_t *d_off, size_t nitems,

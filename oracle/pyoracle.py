@@ -54,6 +54,8 @@ def lib():
         L.rro_accepts.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         L.rro_match_lines.restype = C.c_size_t
         L.rro_match_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.rro_search_lines.restype = C.c_size_t
+        L.rro_search_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
         _LIB = L
     return _LIB
 
@@ -129,3 +131,16 @@ class OracleRegex:
         got = lib().rro_match_lines(self._h, a.ctypes.data if n else None, n, out.ctypes.data, nlines)
         assert got == nlines, (got, nlines)
         return out[:nlines]
+
+    def search_lines(self, data):
+        """Per line the accepted substring [start, end) with the smallest end, then the smallest start (-1, -1 if none).
+        Brute force over substrings with the reference's whole-string acceptance: short lines only."""
+        import numpy as np
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+        n = len(a)
+        nlines = int((a == 10).sum()) + (1 if n and a[-1] != 10 else 0)
+        st = np.full(max(nlines, 1), -1, dtype=np.int32)
+        en = np.full(max(nlines, 1), -1, dtype=np.int32)
+        got = lib().rro_search_lines(self._h, a.ctypes.data if n else None, n, st.ctypes.data, en.ctypes.data, nlines)
+        assert got == nlines, (got, nlines)
+        return st[:nlines], en[:nlines]

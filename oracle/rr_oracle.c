@@ -560,3 +560,25 @@ size_t rro_match_lines(const rro_nfa *n, const uint8_t *bytes, size_t nbytes, ui
     }
     return line;
 }
+
+/* Search restated on top of whole-string acceptance (the reference has no search): the match of a
+ * line is the substring [s, e) the reference ACCEPTS with the smallest e, and among those the smallest s.  Brute
+ * force over (e, s): test infrastructure for short lines only. */
+size_t rro_search_lines(const rro_nfa *n, const uint8_t *bytes, size_t nbytes, int32_t *start, int32_t *end, size_t cap) {
+    size_t line = 0, ls = 0;
+    for (size_t i = 0; i <= nbytes; i++) {
+        if (i == nbytes) { if (ls == nbytes) break; }
+        else if (bytes[i] != '\n') continue;
+        if (line < cap) {
+            const size_t len = i - ls;
+            int32_t bs = -1, be = -1;
+            for (size_t e = 0; e <= len && be < 0; e++)
+                for (size_t s = 0; s <= e; s++)
+                    if (rro_accepts(n, bytes + ls + s, e - s)) { bs = (int32_t)s; be = (int32_t)e; break; }
+            start[line] = bs; end[line] = be;
+        }
+        line++;
+        ls = i + 1;
+    }
+    return line;
+}

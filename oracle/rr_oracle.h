@@ -50,6 +50,9 @@ int rro_accepts(const rro_nfa *n, const uint8_t *s, size_t len);
  * rro_accepts per line, write 0/1 per line.  Returns the number of lines (may exceed cap; only cap are
  * written). */
 size_t rro_match_lines(const rro_nfa *n, const uint8_t *bytes, size_t nbytes, uint8_t *accept, size_t cap);
+/* per line: the accepted substring [start, end) with the smallest end, then the smallest start; -1/-1 if none
+ * (brute force on top of rro_accepts: short lines only) */
+size_t rro_search_lines(const rro_nfa *n, const uint8_t *bytes, size_t nbytes, int32_t *start, int32_t *end, size_t cap);
 
 /* ---- set primitives of the dense classes, exposed so tests can pin them against oracle/_ref ---- */
 /* BitSet.cc:8-21 / 22-35 / 36-41 / 98-115 / 167-180 / 42-56 / 57-97, W in {1,2,4}. */

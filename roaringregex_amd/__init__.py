@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.environ.get("RRX_LIB") or os.path.join(_HERE, "librrx.so")   # RRX_LIB: A/B builds of the same ABI
 
 ENGINE_AUTO, ENGINE_NFA, ENGINE_DFA, ENGINE_DFA_GLOBAL, ENGINE_NFA_WAVE, ENGINE_DFA2 = 0, 1, 2, 3, 4, 5
+PROGRAM_SEARCH_FWD, PROGRAM_SEARCH_REV = 6, 7          # rrx_program_words kinds of the two search tables
 
 # every symbol include/rrx.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = (
@@ -22,7 +23,7 @@ ABI_SYMBOLS = (
     "rrx_engine", "rrx_engine_name", "rrx_useful_states", "rrx_byte_classes", "rrx_words_per_set", "rrx_accepts_empty",
     "rrx_program_words",
     "rrx_corpus_create", "rrx_corpus_create_ex", "rrx_corpus_stripe_bytes", "rrx_corpus_num_lines", "rrx_corpus_num_bytes", "rrx_corpus_free", "rrx_corpus_bitmap_words",
-    "rrx_match_corpus", "rrx_bitmap_to_bytes",
+    "rrx_match_corpus", "rrx_search_corpus", "rrx_bitmap_to_bytes",
     "rrx_match_extents", "rrx_match_string", "rrx_match_host", "rrx_match_cstr",
 )
 
@@ -73,6 +74,7 @@ def _load():
         "rrx_bitmap_to_bytes": (i32, [i32, vp, sz, vp, vp]),
         "rrx_match_extents": (i32, [vp, i32, vp, vp, sz, u32, vp, vp]),
         "rrx_match_string": (i32, [vp, i32, vp, sz, vp, vp]),
+        "rrx_search_corpus": (i32, [vp, vp, vp, vp, vp]),
         "rrx_match_host": (i32, [vp, i32, vp, sz, vp, sz, C.POINTER(sz)]),
         "rrx_match_cstr": (i32, [vp, i32, C.c_char_p, C.POINTER(i32), C.POINTER(sz)]),
     }
@@ -219,6 +221,18 @@ class RRegex:
             _check(_L.rrx_bitmap_to_bytes(corpus.device, C.c_void_p(bits.data_ptr() if n else 0), n,
                                           C.c_void_p(out.data_ptr() if n else 0), _stream_ptr(stream)))
         return out[:n]
+
+    def search_corpus(self, corpus, stream=None):
+        """Per string the accepted substring [start, end) with the smallest end, then the smallest start, as two int32
+        tensors of offsets relative to the start of the string; (-1, -1) where nothing is accepted."""
+        import torch
+        n = corpus.num_lines
+        start = torch.empty(n, dtype=torch.int32, device=corpus.data.device)
+        end = torch.empty(n, dtype=torch.int32, device=corpus.data.device)
+        with torch.cuda.device(corpus.device):
+            _check(_L.rrx_search_corpus(self._h, corpus._h, C.c_void_p(start.data_ptr() if n else 0), C.c_void_p(end.data_ptr() if n else 0),
+                                        _stream_ptr(stream)))
+        return start, end
 
     def match_extents(self, data, offsets, trim=0, out=None, stream=None):
         """item i = data[offsets[i] : offsets[i+1] - trim]; '\\n' is an ordinary character."""

@@ -36,6 +36,11 @@ struct DeviceTables {
     dev::Dfa2Device dfa2;        // stride-2 line-mode table (corpora without bytes >= 0x80)
 };
 
+struct SearchTablesOnDevice {
+    void *blob = nullptr;
+    dev::SearchDevice dev;
+};
+
 int instantiated_width(uint32_t W) { return W <= 4 ? (int)W : W <= 6 ? 6 : W <= 8 ? 8 : W <= 12 ? 12 : 16; }
 
 }  // namespace
@@ -56,9 +61,51 @@ struct rrx_regex {
     bool line_global = false;    // DFA engine: class-indexed table too large for LDS, kept in global memory
     mutable std::mutex mu;
     mutable std::map<int, DeviceTables> on_device;
+    // search (built on first use): the forward "anything, then the pattern" DFA and the reverse DFA
+    mutable int search_state = 0;        // 0 = not built, 1 = built, -1 = does not fit
+    mutable DfaProgram search_fwd, search_rev;
+    mutable std::map<int, SearchTablesOnDevice> search_on_device;
 
     ~rrx_regex() {
         for (auto &kv : on_device) if (kv.second.blob) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.blob); }
+        for (auto &kv : search_on_device) if (kv.second.blob) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.blob); }
+    }
+
+    int build_search() const {           // call with `mu` held
+        if (search_state == 0) {
+            const Reduced red = reduce(trimmed);
+            const bool ok = search_dfas(red, kMaxSubsetStates, search_fwd, search_rev);
+            dev::SearchDevice probe;
+            probe.nf = search_fwd.nstates; probe.nr = search_rev.nstates; probe.ncls = search_fwd.ncls;
+            search_state = ok && dev::search_lds_bytes(probe) <= dev::kSearchLdsBudget ? 1 : -1;
+        }
+        return search_state == 1 ? RRX_OK : fail(RRX_ERR_UNSUPPORTED, "search tables too large for the device (forward + reverse DFA must fit 64 KiB of LDS)");
+    }
+    int search_tables(int device, const dev::SearchDevice **out) const {
+        std::lock_guard<std::mutex> lock(mu);
+        int rc = build_search();
+        if (rc) return rc;
+        auto it = search_on_device.find(device);
+        if (it != search_on_device.end()) { *out = &it->second.dev; return RRX_OK; }
+        HIP_TRY(hipSetDevice(device));
+        std::vector<uint8_t> host;
+        auto put = [&](const void *p, size_t n) { size_t off = (host.size() + 15) & ~(size_t)15; host.resize(off + n); std::memcpy(host.data() + off, p, n); return off; };
+        const size_t oC = put(search_fwd.cls, 256);
+        const size_t oNF = put(search_fwd.next.data(), search_fwd.next.size() * 2), oNR = put(search_rev.next.data(), search_rev.next.size() * 2);
+        const size_t oAF = put(search_fwd.accepting.data(), search_fwd.accepting.size()), oAR = put(search_rev.accepting.data(), search_rev.accepting.size());
+        SearchTablesOnDevice t;
+        HIP_TRY(hipMalloc(&t.blob, host.size()));
+        hipError_t e = hipMemcpy(t.blob, host.data(), host.size(), hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(t.blob); return hip_fail(e, "search table upload"); }
+        const uint8_t *base = static_cast<const uint8_t *>(t.blob);
+        t.dev.nf = search_fwd.nstates; t.dev.nr = search_rev.nstates; t.dev.ncls = search_fwd.ncls;
+        t.dev.start_f = search_fwd.start; t.dev.start_r = search_rev.start;
+        t.dev.cls = base + oC;
+        t.dev.next_f = reinterpret_cast<const uint16_t *>(base + oNF); t.dev.next_r = reinterpret_cast<const uint16_t *>(base + oNR);
+        t.dev.acc_f = base + oAF; t.dev.acc_r = base + oAR;
+        auto ins = search_on_device.emplace(device, t);
+        *out = &ins.first->second.dev;
+        return RRX_OK;
     }
 
     // Upload the program for `device` once; returns the device-side descriptors.
@@ -294,8 +341,12 @@ size_t rrx_program_words(const rrx_regex *re, int kind, uint32_t *out, size_t ca
         w = {d.nstates, d.ncols, d.start, d.accepts_empty ? 1u : 0u};
         for (uint16_t c : d.pair_col) w.push_back(c);
         w.insert(w.end(), d.next2.begin(), d.next2.end());
-    } else if (kind == RRX_ENGINE_DFA && re->has_dfa) {
-        const DfaProgram &d = re->dfa;
+    } else if ((kind == RRX_ENGINE_DFA && re->has_dfa) || kind == RRX_PROGRAM_SEARCH_FWD || kind == RRX_PROGRAM_SEARCH_REV) {
+        if (kind != RRX_ENGINE_DFA) {
+            std::lock_guard<std::mutex> lock(re->mu);
+            if (re->build_search()) return 0;
+        }
+        const DfaProgram &d = kind == RRX_ENGINE_DFA ? re->dfa : kind == RRX_PROGRAM_SEARCH_FWD ? re->search_fwd : re->search_rev;
         w = {d.nstates, d.ncls, d.start, d.accepts_empty ? 1u : 0u};
         for (int c = 0; c < 256; c++) w.push_back(d.cls[c]);
         for (uint8_t a : d.accepting) w.push_back(a);
@@ -374,6 +425,18 @@ int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accep
                 ? dev::match_stripes_dfa2(t->dfa2, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream)
                 : dev::match_stripes_dfa(t->line, c->has_high, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream);
     if (e) return hip_fail((hipError_t)e, "match_stripes launch");
+    return RRX_OK;
+}
+
+int rrx_search_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_start, uint32_t *d_end, void *stream) {
+    if (!re || !c || (c->nlines && (!d_start || !d_end))) return fail(RRX_ERR_ARG, "null argument");
+    const dev::SearchDevice *t;
+    int rc = re->search_tables(c->device, &t);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->nlines) return RRX_OK;
+    int e = dev::search_stripes(*t, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_start, d_end, stream);
+    if (e) return hip_fail((hipError_t)e, "search_stripes launch");
     return RRX_OK;
 }
 

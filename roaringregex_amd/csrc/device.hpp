@@ -113,6 +113,20 @@ int match_extents_wave_nfa(const WaveNfaDevice &p, const uint8_t *bytes, const u
                            uint8_t *accept, void *stream);
 
 // items i = bytes[off[i] .. off[i+1] - trim) ; trim = 1 drops a trailing delimiter byte per item
+// Search (the reference has acceptance only): two plain DFAs over the same byte classes.  fwd = "any bytes, then the
+// pattern" (never dies; accepting where some match ends), rev = the pattern read right to left (accepting, walking back
+// from a match end, where a match starts).  Per line: the match [s, e) with the smallest e, then the smallest s.
+struct SearchDevice {
+    uint32_t nf = 0, nr = 0, ncls = 0, start_f = 0, start_r = 0;
+    const uint8_t *cls = nullptr;                // [256]
+    const uint16_t *next_f = nullptr, *next_r = nullptr;     // [n][ncls]
+    const uint8_t *acc_f = nullptr, *acc_r = nullptr;        // [n]
+};
+constexpr uint32_t kSearchLdsBudget = 64 * 1024;
+size_t search_lds_bytes(const SearchDevice &p);
+int search_stripes(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
+                   size_t nstripes, uint32_t *match_start, uint32_t *match_end, void *stream);
+
 // One long string (regex.h:156-159 consumes it byte by byte): the string is cut into chunks, every chunk is stepped
 // from EVERY table state at once (lane = (chunk, start state); the lanes of a chunk read the same text), which yields
 // one state -> state map per chunk; maps are then composed in groups until one is left.  `scratch` holds the maps.

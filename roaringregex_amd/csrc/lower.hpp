@@ -96,4 +96,9 @@ bool lower_nfa(const Reduced &r, uint32_t max_bits, NfaProgram &out, bool allow_
 // Returns false if subset construction exceeds max_states.
 bool lower_dfa(const Reduced &r, uint32_t max_states, DfaProgram &out);
 
+// Search (the reference has acceptance only).  fwd: the DFA of "any bytes, then the pattern" - no
+// byte kills it, it is accepting exactly at the positions where some match ends.  rev: the DFA of the pattern read
+// right to left - walked backwards from a match end it is accepting exactly at the positions where a match starts.
+bool search_dfas(const Reduced &r, uint32_t max_states, DfaProgram &fwd, DfaProgram &rev);
+
 }  // namespace rrx

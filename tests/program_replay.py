@@ -82,3 +82,31 @@ class Dfa2Replay:
             for k in range(lines):
                 out.append((verdicts >> (lines - 1 - k)) & 1)
         return out[:-1] if drop_last else out
+
+
+class SearchReplay:
+    """The two search tables (rrx_program_words kinds 6 and 7, DFA layout) replayed the way search_stripes_kernel runs
+    them: forward until accepting = smallest match end; then backwards from there, last accepting position = smallest
+    start.  No byte kills the forward table; class 0 kills the reverse one (state 0)."""
+
+    def __init__(self, fwd_words, rev_words):
+        self.f, self.r = DfaReplay(fwd_words), DfaReplay(rev_words)
+
+    def search(self, line):
+        f, r = self.f, self.r
+        q = f.start
+        if f.acc[q]:
+            return 0, 0
+        for i, c in enumerate(line):
+            q = int(f.next[q, f.cls[c]])
+            if f.acc[q]:
+                e = i + 1
+                s, st = e, r.start
+                for k in range(e - 1, -1, -1):
+                    st = int(r.next[st, r.cls[line[k]]])
+                    if st == 0:
+                        break
+                    if r.acc[st]:
+                        s = k
+                return s, e
+        return -1, -1

@@ -401,3 +401,69 @@ def test_one_long_string_is_stepped_in_parallel_chunks():
     m = it.value()
     assert m is not None and (m.start, m.end) == (0, len(s))
     assert r.get_acceptance_iter(s + b"a").advance().value() is None
+
+
+# ------------------------------------------------------------------------------------------ search
+def _check_search(pattern, data, want_start, want_end, stripes=(0,)):
+    dev = torch.from_numpy(np.array(np.frombuffer(data, dtype=np.uint8), copy=True)).cuda()
+    r = rr.RRegex(pattern)
+    for stripe in stripes:
+        corpus = rr.Corpus(dev, stripe=stripe)
+        assert corpus.num_lines == len(want_start)
+        s, e = r.search_corpus(corpus)
+        s, e = s.cpu().numpy(), e.cpu().numpy()
+        bad = np.nonzero((s != want_start) | (e != want_end))[0]
+        assert bad.size == 0, (pattern[:40], "stripe", corpus.stripe, "line", int(bad[0]), (int(s[bad[0]]), int(e[bad[0]])),
+                               "want", (int(want_start[bad[0]]), int(want_end[bad[0]])))
+
+
+def test_search_corpus_short_lines_against_the_oracle():
+    """rrx_search_corpus: per line the accepted substring with the smallest end, then the smallest start.  The oracle
+    finds it by brute force with the reference's whole-string acceptance (short lines only)."""
+    rng = random.Random(77)
+    pats = ["ab+c", "a*", "(a|b)*abb", "[0-9]+\\.[0-9]+", "x?y?z?", "k(1|10|100)", "a{2,4}b", ".*c", "c.*", "[^a]b", EMAIL, U2]
+    while len(pats) < 40:
+        p = random_pattern(rng)
+        try:
+            if OracleRegex(p).states_n <= 120:
+                pats.append(p)
+        except OracleError:
+            pass
+    for p in pats:
+        o = OracleRegex(p)
+        alphabet = "abcxk01.d@yz" if p not in (EMAIL, U2) else "ab1.@:/hftps"
+        lines = ["".join(rng.choice(alphabet) for _ in range(rng.choice([0, 0, 1, 2, 5, 9, 14, 22]))).encode() for _ in range(3000)]
+        lines[5] = b"\x80ab" + lines[5]
+        lines[9] = lines[9] + b"\xc3\xa9" + lines[10]
+        for tail in (b"\n", b""):
+            data = b"\n".join(lines) + tail
+            ws, we = o.search_lines(data)
+            _check_search(p, data, ws, we, stripes=(1024, 4096))
+    # degenerate inputs
+    for data in (b"\n", b"\n\n\n", b"a", b"abc\n"):
+        ws, we = OracleRegex("ab?").search_lines(data)
+        _check_search("ab?", data, ws, we)
+    r = rr.RRegex("ab")
+    s, e = r.search_corpus(rr.Corpus(torch.empty(0, dtype=torch.uint8, device="cuda")))
+    assert s.numel() == 0 and e.numel() == 0
+
+
+def test_search_corpus_long_lines_across_stripes():
+    """Lines far longer than a stripe (matches found after, at and across stripe boundaries; the walk back to the match
+    start crosses them too), checked with the CPU replay of the same two tables, which tests/test_lowering.py pins to
+    the oracle."""
+    from program_replay import SearchReplay
+    rng = random.Random(5)
+    for p in ("ab+c", "[0-9]+\\.[0-9]+", "b(a|c)*d", U2):
+        r = rr.RRegex(p)
+        rep = SearchReplay(r.program(rr.PROGRAM_SEARCH_FWD), r.program(rr.PROGRAM_SEARCH_REV))
+        needle = {"ab+c": b"abbbbc", "[0-9]+\\.[0-9]+": b"12345.678", "b(a|c)*d": b"b" + b"ac" * 700 + b"d", U2: b"http://www.example.com/a/b"}[p]
+        lines = []
+        for n in (0, 1, 1000, 1017, 1024, 1030, 2048, 3000, 4090, 4096, 5000, 9000, 17000):
+            filler = bytes(rng.choice(b"xyz ") for _ in range(n))
+            lines += [filler + needle + b" tail", filler, needle + filler, filler[: n // 2] + needle[:3] + filler[n // 2:] + needle]
+        data = b"\n".join(lines)
+        want = [rep.search(ln) for ln in lines]
+        ws = np.array([w[0] for w in want], dtype=np.int32)
+        we = np.array([w[1] for w in want], dtype=np.int32)
+        _check_search(p, data, ws, we, stripes=STRIPES)

@@ -236,3 +236,35 @@ def test_host_pipeline_is_clean_under_asan_and_ubsan(tmp_path):
         except rr.RRegexError as e:
             ok = "too large" in str(e)               # compiled, but no device engine admits it
         assert ok == (" ok " in line), (p[:60], line)
+
+
+def test_search_tables_find_the_earliest_ending_leftmost_match():
+    """Search has no counterpart in the reference's code; it is pinned to the reference's ACCEPTANCE:
+    the oracle tries every substring with whole-string acceptance (smallest end, then smallest start).  The forward
+    and reverse tables are replayed on the CPU exactly as the device kernel runs them."""
+    from program_replay import SearchReplay
+    rng = random.Random(31)
+    pats = ["ab+c", "a*", "(a|b)*abb", "[0-9]+\\.[0-9]+", "x?y?z?", "k(1|10|100)", "a{2,4}b", ".*c", "c.*", "(ab|b)a?", "[^a]b", EMAIL, U2]
+    done = 0
+    while done < 40:
+        p = random_pattern(rng)
+        try:
+            if OracleRegex(p).states_n <= 120:
+                pats.append(p)
+                done += 1
+        except OracleError:
+            pass
+    for p in pats:
+        o = OracleRegex(p)
+        r = rr.RRegex(p)
+        fw, rv = r.program(rr.PROGRAM_SEARCH_FWD), r.program(rr.PROGRAM_SEARCH_REV)
+        assert fw is not None and rv is not None, p
+        rep = SearchReplay(fw, rv)
+        alphabet = "abcxk01.d@yz" if p not in (EMAIL, U2) else "ab1.@:/hftps"
+        lines = [bytes(ord(ch) for ch in "".join(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 2, 5, 9, 14])))) for _ in range(60)]
+        if p == U2:
+            lines += [b"see http://a.b/c ok", b"xxftp://h.io", b"https://"]
+        lines += [b"\x80ab" + lines[0], lines[1] + b"\xc3\xa9" + lines[2]]          # bytes outside the domain are ordinary text
+        st, en = o.search_lines(b"\n".join(lines) + b"\n")
+        for ln, s, e in zip(lines, st, en):
+            assert rep.search(ln) == (int(s), int(e)), (p[:50], ln, (int(s), int(e)))
