@@ -77,7 +77,7 @@ struct rrx_regex {
             const bool ok = search_dfas(red, kMaxSubsetStates, search_fwd, search_rev);
             dev::SearchDevice probe;
             probe.nf = search_fwd.nstates; probe.nr = search_rev.nstates; probe.ncls = search_fwd.ncls;
-            search_state = ok && dev::search_lds_bytes(probe) <= dev::kSearchLdsBudget ? 1 : -1;
+            search_state = ok && dev::search_lds_bytes(probe) <= dev::kSearchLdsBudget && probe.nf <= 32767 && probe.nr <= 32767 ? 1 : -1;
         }
         return search_state == 1 ? RRX_OK : fail(RRX_ERR_UNSUPPORTED, "search tables too large for the device (forward + reverse DFA must fit 64 KiB of LDS)");
     }
@@ -247,6 +247,9 @@ struct rrx_corpus {
     uint32_t *d_counts = nullptr;   // [nstripes] newlines per stripe, then one flags word
     uint64_t *d_base = nullptr;     // [nstripes+1] exclusive prefix
     bool has_high = false;          // some byte >= 0x80 occurs
+    // search only: offset of the first byte of every line, built on the first search of this corpus
+    mutable std::mutex mu;
+    mutable uint64_t *d_line_off = nullptr;     // [nlines + 1]
 };
 
 static constexpr size_t kLongStringBytes = 32 * 1024;   // shorter single strings stay on one lane
@@ -403,6 +406,7 @@ void rrx_corpus_free(rrx_corpus *c) {
     (void)hipSetDevice(c->device);
     if (c->d_counts) (void)hipFree(c->d_counts);
     if (c->d_base) (void)hipFree(c->d_base);
+    if (c->d_line_off) (void)hipFree(c->d_line_off);
     delete c;
 }
 
@@ -435,8 +439,24 @@ int rrx_search_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_star
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
     if (!c->nlines) return RRX_OK;
-    int e = dev::search_stripes(*t, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_start, d_end, stream);
-    if (e) return hip_fail((hipError_t)e, "search_stripes launch");
+    {
+        std::lock_guard<std::mutex> lock(c->mu);
+        if (!c->d_line_off) {
+            uint64_t *off = nullptr;
+            HIP_TRY(hipMalloc(reinterpret_cast<void **>(&off), (c->nlines + 1) * sizeof(uint64_t)));
+            // entry nlines: one past the last '\n' - the kernel writes it when the corpus ends in '\n'; otherwise the
+            // last line ends at the end of the data, as if a '\n' followed it
+            const uint64_t past = (uint64_t)c->nbytes + 1;
+            hipError_t he = hipMemcpyAsync(off + c->nlines, &past, sizeof past, hipMemcpyHostToDevice, (hipStream_t)stream);
+            if (he == hipSuccess) he = hipStreamSynchronize((hipStream_t)stream);          // `past` leaves scope
+            int le = he == hipSuccess ? dev::build_line_offsets(c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, off, stream) : 0;
+            if (he == hipSuccess && !le) he = hipStreamSynchronize((hipStream_t)stream);   // once per corpus: later searches may use other streams
+            if (he != hipSuccess || le) { (void)hipFree(off); return he != hipSuccess ? hip_fail(he, "line offsets") : hip_fail((hipError_t)le, "line_offsets launch"); }
+            c->d_line_off = off;
+        }
+    }
+    int e = dev::search_lines(*t, c->d_bytes, c->nbytes, c->d_line_off, c->nlines, d_start, d_end, stream);
+    if (e) return hip_fail((hipError_t)e, "search_lines launch");
     return RRX_OK;
 }
 

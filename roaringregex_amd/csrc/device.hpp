@@ -124,8 +124,13 @@ struct SearchDevice {
 };
 constexpr uint32_t kSearchLdsBudget = 64 * 1024;
 size_t search_lds_bytes(const SearchDevice &p);
-int search_stripes(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
-                   size_t nstripes, uint32_t *match_start, uint32_t *match_end, void *stream);
+// line_off[i] = offset of the first byte of line i (built once per corpus from the stripe index); nlines + 1 entries are
+// the caller's to size, entry nlines is written only when the corpus ends in '\n'.
+int build_line_offsets(const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base, size_t nstripes,
+                       uint64_t *line_off, void *stream);
+// one lane per line: line i = bytes[line_off[i] .. line_off[i+1] - 1)
+int search_lines(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *line_off, size_t nlines,
+                 uint32_t *match_start, uint32_t *match_end, void *stream);
 
 // One long string (regex.h:156-159 consumes it byte by byte): the string is cut into chunks, every chunk is stepped
 // from EVERY table state at once (lane = (chunk, start state); the lanes of a chunk read the same text), which yields

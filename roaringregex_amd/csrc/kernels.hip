@@ -943,98 +943,100 @@ int launch_stripes(const Program &p, size_t table_bytes, const uint8_t *bytes, s
 }
 
 // ============================================================================================ search
-// Lane = stripe, same ownership rule as the match kernels (a line belongs to the lane in whose stripe it starts; the
-// lane follows its last line past the stripe end).  Per owned line: step the forward DFA until it accepts (that is the
-// smallest match end e), then walk the reverse DFA back from e to the line start, remembering the last position where
-// it accepts (the smallest start of a match that ends at e).  After the match the lane only looks for the '\n'.
-// First version: byte loop, two scattered 4-byte stores per line; not tuned.
+// Two kernels.  line_offsets_kernel (once per corpus): lane = stripe, every '\n' at p inside the stripe starts the next
+// line at p + 1 (line numbers from the stripe index).  search_lines_kernel: lane = line.  Step the forward DFA until it
+// accepts (that is the smallest match end e) and stop there - a lane never reads the rest of its line - then walk the
+// reverse DFA back from e to the line start, remembering the last position where it accepts (the smallest start of a
+// match that ends at e).  Consecutive lanes own consecutive lines: their text is contiguous and both result arrays are
+// written coalesced.
+__global__ __launch_bounds__(256) void line_offsets_kernel(const uint8_t *__restrict__ bytes, size_t nbytes, uint32_t stripe,
+                                                           const uint64_t *__restrict__ stripe_base, size_t nstripes,
+                                                           uint64_t *__restrict__ line_off) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nstripes) return;
+    const size_t start = g * (size_t)stripe, end = start + stripe < nbytes ? start + stripe : nbytes;
+    uint64_t line = stripe_base[g];                      // index of the line that contains my first byte
+    if (g == 0) line_off[0] = 0;
+    size_t pos = start;
+    for (; pos + 16 <= end; pos += 16) {                 // stripes start 16-byte aligned
+        const uint4 v = *reinterpret_cast<const uint4 *>(bytes + pos);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t x = w[j] ^ 0x0a0a0a0au;
+            uint32_t hit = (x - 0x01010101u) & ~x & 0x80808080u;        // exact for the lowest flagged byte; refined below
+            while (hit) {
+                const int k = (__ffs((int)hit) - 1) >> 3;
+                if (((w[j] >> (8 * k)) & 0xffu) == '\n') line_off[++line] = pos + 4 * j + k + 1;
+                hit &= hit - 1;
+            }
+        }
+    }
+    for (; pos < end; pos++)
+        if (bytes[pos] == '\n') line_off[++line] = pos + 1;
+}
+
 struct SearchTables {
-    const uint8_t *cls, *acc_f, *acc_r;
-    const uint16_t *next_f, *next_r;
+    const uint8_t *cls;
+    const uint16_t *next_f, *next_r;                     // bit 15 of an entry = the state it leads to is accepting
     uint32_t K, start_f, start_r;
+    bool empty_matches;
     __device__ void load(const SearchDevice &p, uint8_t *lds) {
         uint16_t *nf = reinterpret_cast<uint16_t *>(lds);
         uint16_t *nr = nf + (size_t)p.nf * p.ncls;
         uint8_t *c = reinterpret_cast<uint8_t *>(nr + (size_t)p.nr * p.ncls);
-        uint8_t *af = c + 256, *ar = af + p.nf;
-        for (uint32_t i = threadIdx.x; i < p.nf * p.ncls; i += blockDim.x) nf[i] = p.next_f[i];
-        for (uint32_t i = threadIdx.x; i < p.nr * p.ncls; i += blockDim.x) nr[i] = p.next_r[i];
+        for (uint32_t i = threadIdx.x; i < p.nf * p.ncls; i += blockDim.x) { const uint16_t t = p.next_f[i]; nf[i] = (uint16_t)(t | (p.acc_f[t] ? 0x8000u : 0u)); }
+        for (uint32_t i = threadIdx.x; i < p.nr * p.ncls; i += blockDim.x) { const uint16_t t = p.next_r[i]; nr[i] = (uint16_t)(t | (p.acc_r[t] ? 0x8000u : 0u)); }
         for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) c[i] = p.cls[i];
-        for (uint32_t i = threadIdx.x; i < p.nf; i += blockDim.x) af[i] = p.acc_f[i];
-        for (uint32_t i = threadIdx.x; i < p.nr; i += blockDim.x) ar[i] = p.acc_r[i];
-        cls = c; acc_f = af; acc_r = ar; next_f = nf; next_r = nr; K = p.ncls; start_f = p.start_f; start_r = p.start_r;
+        cls = c; next_f = nf; next_r = nr; K = p.ncls; start_f = p.start_f; start_r = p.start_r;
+        empty_matches = p.acc_f[p.start_f] != 0;
     }
 };
-struct SearchLine {                      // the line a lane is currently inside
-    size_t line_start;
-    uint32_t q;                          // forward state
-    bool found;
-    uint32_t s, e;                       // the match, relative to line_start
-};
-__global__ __launch_bounds__(256) void search_stripes_kernel(SearchDevice prog, const uint8_t *__restrict__ bytes, size_t nbytes,
-                                                             uint32_t stripe, const uint64_t *__restrict__ stripe_base,
-                                                             uint32_t *__restrict__ match_start, uint32_t *__restrict__ match_end) {
+__global__ __launch_bounds__(256) void search_lines_kernel(SearchDevice prog, const uint8_t *__restrict__ bytes, size_t nbytes,
+                                                           const uint64_t *__restrict__ line_off, size_t nlines,
+                                                           uint32_t *__restrict__ match_start, uint32_t *__restrict__ match_end) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     SearchTables t;
     t.load(prog, smem);
     __syncthreads();
-    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t start = g * (size_t)stripe;
-    if (start >= nbytes) return;
-    const size_t stripe_end = start + stripe;
-    const size_t my_end = stripe_end < nbytes ? stripe_end : nbytes;
-    bool owning = start == 0 || bytes[start - 1] == '\n';
-    uint64_t line = stripe_base[g];                      // index of the line that contains my first byte
-    SearchLine L;
-    auto begin_line = [&](size_t at) {
-        L.line_start = at; L.q = t.start_f; L.found = t.acc_f[t.start_f] != 0; L.s = 0; L.e = 0;       // the empty match
-    };
-    auto emit = [&]() {
-        match_start[line] = L.found ? L.s : 0xffffffffu;
-        match_end[line] = L.found ? L.e : 0xffffffffu;
-    };
-    auto feed = [&](size_t pos, uint32_t c) {            // one byte of an owned line, not a '\n'
-        if (L.found) return;
-        L.q = t.next_f[L.q * t.K + t.cls[c]];
-        if (!t.acc_f[L.q]) return;
-        L.found = true;
-        L.e = (uint32_t)(pos + 1 - L.line_start);
-        uint32_t r = t.start_r;
-        size_t best = pos + 1;                           // (start_r accepting <=> the pattern accepts "", handled at begin_line)
-        for (size_t k = pos + 1; k > L.line_start;) {
-            k--;
-            r = t.next_r[r * t.K + t.cls[bytes[k]]];
-            if (!r) break;                               // state 0 is dead
-            if (t.acc_r[r]) best = k;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nlines) return;
+    const size_t a = line_off[i], b = line_off[i + 1] - 1;        // [a, b): the line without its '\n'
+    uint32_t s = 0xffffffffu, e = 0xffffffffu;
+    if (t.empty_matches) {
+        s = 0; e = 0;                                             // the pattern accepts "": the match is [0, 0)
+    } else {
+        uint32_t q = t.start_f;
+        size_t pos = a;
+        bool found = false;
+        while (pos < b && !found) {                               // aligned dwords; bytes before `pos` / from `b` on are skipped
+            const size_t base = pos & ~(size_t)3;
+            uint32_t w;
+            if (base + 4 <= nbytes) w = *reinterpret_cast<const uint32_t *>(bytes + base);
+            else { w = 0; for (size_t k = pos; k < nbytes; k++) w |= (uint32_t)bytes[k] << (8 * (k - base)); }     // last dword of the data
+            const size_t stop = base + 4 < b ? base + 4 : b;
+            for (; pos < stop; pos++) {
+                const uint32_t x = t.next_f[q * t.K + t.cls[(w >> (8 * (pos - base))) & 0xffu]];
+                q = x & 0x7fffu;
+                if (x & 0x8000u) { found = true; pos++; break; }
+            }
         }
-        L.s = (uint32_t)(best - L.line_start);
-    };
-    if (owning) begin_line(start);
-    size_t pos = start;
-    auto one = [&](uint32_t c) {
-        if (c == '\n') {
-            if (owning) emit();
-            line++;
-            owning = true;
-            begin_line(pos + 1);
-        } else if (owning) {
-            feed(pos, c);
+        if (found) {
+            e = (uint32_t)(pos - a);
+            uint32_t r = t.start_r;
+            size_t best = pos;
+            for (size_t k = pos; k > a;) {
+                k--;
+                const uint32_t x = t.next_r[r * t.K + t.cls[bytes[k]]];
+                r = x & 0x7fffu;
+                if (!r) break;                                    // state 0 is dead
+                if (x & 0x8000u) best = k;
+            }
+            s = (uint32_t)(best - a);
         }
-        pos++;
-    };
-    for (; pos < my_end && (pos & 15);) one(bytes[pos]);
-    for (; pos + 16 <= my_end;) {
-        const uint4 v = *reinterpret_cast<const uint4 *>(bytes + pos);
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-        for (int k = 0; k < 16; k++) one((w[k >> 2] >> (8 * (k & 3))) & 0xffu);
     }
-    for (; pos < my_end;) one(bytes[pos]);
-    // my last line continues past the stripe end unless the stripe ended exactly on its '\n'
-    if (owning && bytes[my_end - 1] != '\n') {
-        for (; pos < nbytes && bytes[pos] != '\n'; pos++) feed(pos, bytes[pos]);
-        emit();                                          // ended by its '\n' or by the end of the data
-    }
+    match_start[i] = s;
+    match_end[i] = e;
 }
 
 // ============================================================================================ one long string
@@ -1181,18 +1183,22 @@ int match_extents_nfa(const NfaDevice &p, const uint8_t *bytes, const uint64_t *
     RRX_NFA_DISPATCH(CALL)
 #undef CALL
 }
-size_t search_lds_bytes(const SearchDevice &p) {
-    return ((size_t)p.nf + p.nr) * p.ncls * sizeof(uint16_t) + 256 + p.nf + p.nr;
-}
-int search_stripes(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
-                   size_t nstripes, uint32_t *match_start, uint32_t *match_end, void *stream) {
+size_t search_lds_bytes(const SearchDevice &p) { return ((size_t)p.nf + p.nr) * p.ncls * sizeof(uint16_t) + 256; }
+int build_line_offsets(const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base, size_t nstripes,
+                       uint64_t *line_off, void *stream) {
     if (!nstripes) return 0;
+    hipLaunchKernelGGL(line_offsets_kernel, dim3((unsigned)((nstripes + 255) / 256)), dim3(256), 0, (hipStream_t)stream, bytes, nbytes, stripe,
+                       stripe_base, nstripes, line_off);
+    return (int)hipGetLastError();
+}
+int search_lines(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *line_off, size_t nlines, uint32_t *match_start,
+                 uint32_t *match_end, void *stream) {
+    if (!nlines) return 0;
     const size_t lds = search_lds_bytes(p);
-    if (lds > kSearchLdsBudget) return (int)hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(search_stripes_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (lds > kSearchLdsBudget || p.nf > 32767 || p.nr > 32767) return (int)hipErrorInvalidValue;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(search_lines_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    size_t blocks = (nstripes + 255) / 256;
-    hipLaunchKernelGGL(search_stripes_kernel, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base,
+    hipLaunchKernelGGL(search_lines_kernel, dim3((unsigned)((nlines + 255) / 256)), dim3(256), lds, (hipStream_t)stream, p, bytes, nbytes, line_off, nlines,
                        match_start, match_end);
     return (int)hipGetLastError();
 }
