@@ -535,8 +535,14 @@ struct Dfa2 {
         asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(ia) : "v"(ta), "v"(w2));
         asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(tb) : "v"(w2), "v"(stride));
         asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(ib) : "v"(tb), "v"(w2));
-#ifdef RRX_PROBE_NO_LOOKUP      /* measurement only: same feed, VALU work and result path, no LDS gathers (results are wrong) */
+#if defined(RRX_PROBE_NO_LOOKUP)    /* measurement only: same feed, VALU work and result path, no LDS gathers (results are wrong) */
 #define RRX_LDS_U16(x) ((x) & 0x3cu)
+#define RRX_LDS_U32(x) ((x) & 0x0001ffffu)
+#elif defined(RRX_PROBE_NO_P)       /* measurement only: no pair-table gather (results are wrong) */
+#define RRX_LDS_U16(x) ((x) & 0x3cu)
+#define RRX_LDS_U32(x) (*reinterpret_cast<lds_u32_ptr>(x))
+#elif defined(RRX_PROBE_NO_T2)      /* measurement only: no state-table gather (results are wrong) */
+#define RRX_LDS_U16(x) (*reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(P) + (x)))
 #define RRX_LDS_U32(x) ((x) & 0x0001ffffu)
 #else
 #define RRX_LDS_U16(x) (*reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(P) + (x)))
