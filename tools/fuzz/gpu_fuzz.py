@@ -1,0 +1,66 @@
+"""One-off heavier randomized parity run on a GPU box (not part of the default suite): random patterns x corpora with
+mixed line-length distributions (empty lines, one-byte lines, lines longer than a stripe, bytes outside the domain,
+missing final newline) x every engine x three stripe sizes, against the oracle.  Usage: gpu_fuzz.py [seed] [patterns] [corpus bytes]"""
+import os, random, sys, time
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")]
+import numpy as np, torch
+import roaringregex_amd as rr
+from patterns import random_pattern, random_text
+from pyoracle import OracleError, OracleRegex
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+npat = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+big = int(sys.argv[3]) if len(sys.argv) > 3 else 0          # fixed corpus size in bytes (several workgroups at stripe 1024)
+rng = random.Random(seed)
+t0 = time.time()
+done = checked = 0
+while done < npat:
+    p = random_pattern(rng)
+    try:
+        o = OracleRegex(p)
+    except OracleError:
+        continue
+    if o.states_n > 400:
+        continue
+    engines = []
+    for e in (rr.ENGINE_NFA, rr.ENGINE_DFA, rr.ENGINE_DFA2, rr.ENGINE_DFA_GLOBAL):
+        try:
+            engines.append(rr.RRegex(p, e))
+        except rr.RRegexError:
+            pass
+    if not engines:
+        continue
+    mix = rng.choice(["short", "empty-heavy", "long", "mixed"])
+    lines = []
+    total = 0
+    target = big if big else rng.choice([3000, 40000, 300000])
+    while total < target:
+        if mix == "short": n = rng.choice([0, 1, 2, 3, 5, 8])
+        elif mix == "empty-heavy": n = rng.choice([0, 0, 0, 1, 4])
+        elif mix == "long": n = rng.choice([10, 200, 1500, 5000, 20000])
+        else: n = rng.choice([0, 1, 7, 30, 130, 1100, 4200])
+        s = random_text(rng, "abcxk01.d", n) if n <= 30 else "".join(rng.choice("abcxk01.d") for _ in range(n))
+        b = s.encode()
+        r = rng.random()
+        if r < 0.02 and b: b = b[: len(b) // 2] + bytes([rng.choice([0x80, 0xc3, 0xff, 0x01, 0x7f])]) + b[len(b) // 2:]
+        lines.append(b)
+        total += len(b) + 1
+    data = b"\n".join(lines) + (b"\n" if rng.random() < 0.7 else b"")
+    arr = np.frombuffer(data, dtype=np.uint8)
+    want = o.match_lines(arr)
+    dev = torch.from_numpy(arr.copy()).cuda() if len(arr) else torch.empty(0, dtype=torch.uint8, device="cuda")
+    for stripe in (1024, 4096, 16384):
+        corpus = rr.Corpus(dev, stripe=stripe)
+        assert corpus.num_lines == len(want), (p, corpus.num_lines, len(want))
+        for r_ in engines:
+            got = r_.match_corpus(corpus).cpu().numpy()
+            bad = np.nonzero(got != want)[0]
+            if bad.size:
+                print("MISMATCH", repr(p), r_.engine_name, "stripe", stripe, "mix", mix, "line", int(bad[0]), "of", len(want), flush=True)
+                sys.exit(1)
+            checked += 1
+    done += 1
+    if done % 20 == 0:
+        print("patterns", done, "checks", checked, "%.0f s" % (time.time() - t0), flush=True)
+print("fuzz ok: seed", seed, "patterns", done, "engine x stripe checks", checked)
