@@ -238,6 +238,14 @@ def main():
             torch.cuda.synchronize()
             res["search"] = {"GBs": round(3 * nbytes / (time.perf_counter() - t0) / 1e9, 2), "lines_with_a_match": int((e >= 0).sum().item()),
                              "mean_match_len": round(float((e - s)[e >= 0].double().mean().item()), 2) if int((e >= 0).sum().item()) else 0.0}
+            del s, e
+            cnt, first, s, e = regex.search_all(corpus)          # count pass + prefix sum + fill pass
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            cnt, first, s, e = regex.search_all(corpus)
+            torch.cuda.synchronize()
+            res["search"]["all_matches"] = {"GBs": round(nbytes / (time.perf_counter() - t0) / 1e9, 2), "matches": int(s.numel())}
+            del cnt, first, s, e
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(pattern, host)
         print(json.dumps(res), flush=True)

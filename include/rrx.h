@@ -85,6 +85,13 @@ int rrx_bitmap_to_bytes(int device, const uint32_t *d_accept_bits, size_t nlines
  * 0xFFFFFFFF in both when no substring is accepted.  Bytes the pattern cannot match (including NUL and >= 0x80) are
  * ordinary text here.  RRX_ERR_UNSUPPORTED when the two search tables do not fit the device.                     */
 int rrx_search_corpus(const rrx_regex *re, const rrx_corpus *corpus, uint32_t *d_start, uint32_t *d_end, void *stream);
+/* ALL lazy matches of every string, left to right (what the reference's CLI is documented to print, README.md:30): the
+ * k-th match of a string is the search above applied to the rest of the string after the previous match (one byte
+ * further after an empty match).  Two passes: _count writes d_count[i] = matches of string i; the caller turns the
+ * counts into the exclusive prefix d_first[i] (u64); _fill writes the matches of string i to the slots d_first[i] ...   */
+int rrx_search_all_count(const rrx_regex *re, const rrx_corpus *corpus, uint32_t *d_count, void *stream);
+int rrx_search_all_fill(const rrx_regex *re, const rrx_corpus *corpus, const uint64_t *d_first, uint32_t *d_start,
+                        uint32_t *d_end, void *stream);
 
 /* explicit extents: item i = d_bytes[d_off[i] .. d_off[i+1] - trim); '\n' is an ordinary character here */
 int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, const uint64_t *d_off, size_t nitems,

@@ -54,6 +54,8 @@ def lib():
         L.rro_accepts.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t]
         L.rro_match_lines.restype = C.c_size_t
         L.rro_match_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]
+        L.rro_search_all.restype = C.c_size_t
+        L.rro_search_all.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
         L.rro_search_lines.restype = C.c_size_t
         L.rro_search_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
         _LIB = L
@@ -144,3 +146,17 @@ class OracleRegex:
         got = lib().rro_search_lines(self._h, a.ctypes.data if n else None, n, st.ctypes.data, en.ctypes.data, nlines)
         assert got == nlines, (got, nlines)
         return st[:nlines], en[:nlines]
+
+    def search_all(self, data):
+        """All lazy matches per line, left to right -> (count[nlines] uint32, start[total] int32, end[total] int32),
+        offsets relative to the line.  Brute force: short lines only."""
+        import numpy as np
+        a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, dtype=np.uint8)
+        n = len(a)
+        nlines = int((a == 10).sum()) + (1 if n and a[-1] != 10 else 0)
+        cnt = np.zeros(max(nlines, 1), dtype=np.uint32)
+        cap = n + nlines + 1                                   # a line of n bytes has at most n + 1 matches
+        st = np.full(cap, -1, dtype=np.int32)
+        en = np.full(cap, -1, dtype=np.int32)
+        total = lib().rro_search_all(self._h, a.ctypes.data if n else None, n, cnt.ctypes.data, nlines, st.ctypes.data, en.ctypes.data, cap)
+        return cnt[:nlines], st[:total], en[:total]

@@ -582,3 +582,32 @@ size_t rro_search_lines(const rro_nfa *n, const uint8_t *bytes, size_t nbytes, i
     }
     return line;
 }
+
+/* All lazy matches of a line, left to right: the k-th match is the search above applied to line[p..) where p is the end
+ * of the previous match (one byte further after an empty match).  Writes up to cap (start, end) pairs, flattened over
+ * the lines in order; count[i] = matches of line i.  Returns the total number of matches. */
+size_t rro_search_all(const rro_nfa *n, const uint8_t *bytes, size_t nbytes, uint32_t *count, size_t nlines_cap,
+                      int32_t *start, int32_t *end, size_t cap) {
+    size_t line = 0, ls = 0, total = 0;
+    for (size_t i = 0; i <= nbytes; i++) {
+        if (i == nbytes) { if (ls == nbytes) break; }
+        else if (bytes[i] != '\n') continue;
+        const size_t len = i - ls;
+        uint32_t k = 0;
+        size_t p = 0;
+        while (p <= len) {
+            int64_t bs = -1, be = -1;
+            for (size_t e = p; e <= len && be < 0; e++)
+                for (size_t s = p; s <= e; s++)
+                    if (rro_accepts(n, bytes + ls + s, e - s)) { bs = (int64_t)s; be = (int64_t)e; break; }
+            if (be < 0) break;
+            if (total < cap) { start[total] = (int32_t)bs; end[total] = (int32_t)be; }
+            total++; k++;
+            p = be > bs ? (size_t)be : (size_t)be + 1;
+        }
+        if (line < nlines_cap) count[line] = k;
+        line++;
+        ls = i + 1;
+    }
+    return total;
+}

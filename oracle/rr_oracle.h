@@ -53,6 +53,10 @@ size_t rro_match_lines(const rro_nfa *n, const uint8_t *bytes, size_t nbytes, ui
 /* per line: the accepted substring [start, end) with the smallest end, then the smallest start; -1/-1 if none
  * (brute force on top of rro_accepts: short lines only) */
 size_t rro_search_lines(const rro_nfa *n, const uint8_t *bytes, size_t nbytes, int32_t *start, int32_t *end, size_t cap);
+/* all lazy matches per line, left to right (after a match continue at its end; one byte further after an empty one):
+ * count[line], and the (start, end) pairs flattened in line order (at most cap are written); returns the total */
+size_t rro_search_all(const rro_nfa *n, const uint8_t *bytes, size_t nbytes, uint32_t *count, size_t nlines_cap,
+                      int32_t *start, int32_t *end, size_t cap);
 
 /* ---- set primitives of the dense classes, exposed so tests can pin them against oracle/_ref ---- */
 /* BitSet.cc:8-21 / 22-35 / 36-41 / 98-115 / 167-180 / 42-56 / 57-97, W in {1,2,4}. */

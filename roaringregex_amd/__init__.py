@@ -23,7 +23,7 @@ ABI_SYMBOLS = (
     "rrx_engine", "rrx_engine_name", "rrx_useful_states", "rrx_byte_classes", "rrx_words_per_set", "rrx_accepts_empty",
     "rrx_program_words",
     "rrx_corpus_create", "rrx_corpus_create_ex", "rrx_corpus_stripe_bytes", "rrx_corpus_num_lines", "rrx_corpus_num_bytes", "rrx_corpus_free", "rrx_corpus_bitmap_words",
-    "rrx_match_corpus", "rrx_search_corpus", "rrx_bitmap_to_bytes",
+    "rrx_match_corpus", "rrx_search_corpus", "rrx_search_all_count", "rrx_search_all_fill", "rrx_bitmap_to_bytes",
     "rrx_match_extents", "rrx_match_string", "rrx_match_host", "rrx_match_cstr",
 )
 
@@ -75,6 +75,8 @@ def _load():
         "rrx_match_extents": (i32, [vp, i32, vp, vp, sz, u32, vp, vp]),
         "rrx_match_string": (i32, [vp, i32, vp, sz, vp, vp]),
         "rrx_search_corpus": (i32, [vp, vp, vp, vp, vp]),
+        "rrx_search_all_count": (i32, [vp, vp, vp, vp]),
+        "rrx_search_all_fill": (i32, [vp, vp, vp, vp, vp, vp]),
         "rrx_match_host": (i32, [vp, i32, vp, sz, vp, sz, C.POINTER(sz)]),
         "rrx_match_cstr": (i32, [vp, i32, C.c_char_p, C.POINTER(i32), C.POINTER(sz)]),
     }
@@ -233,6 +235,25 @@ class RRegex:
             _check(_L.rrx_search_corpus(self._h, corpus._h, C.c_void_p(start.data_ptr() if n else 0), C.c_void_p(end.data_ptr() if n else 0),
                                         _stream_ptr(stream)))
         return start, end
+
+    def search_all(self, corpus, stream=None):
+        """ALL lazy matches of every string, left to right -> (count[n] int32, first[n] int64, start[total] int32,
+        end[total] int32): the matches of string i are start/end[first[i] : first[i] + count[i]], relative to the string."""
+        import torch
+        n = corpus.num_lines
+        dev = corpus.data.device
+        count = torch.zeros(n, dtype=torch.int32, device=dev)
+        with torch.cuda.device(corpus.device):
+            _check(_L.rrx_search_all_count(self._h, corpus._h, C.c_void_p(count.data_ptr() if n else 0), _stream_ptr(stream)))
+            inclusive = torch.cumsum(count, dim=0, dtype=torch.int64)
+            first = inclusive - count
+            total = int(inclusive[-1].item()) if n else 0
+            start = torch.empty(total, dtype=torch.int32, device=dev)
+            end = torch.empty(total, dtype=torch.int32, device=dev)
+            if total:
+                _check(_L.rrx_search_all_fill(self._h, corpus._h, C.c_void_p(first.data_ptr()), C.c_void_p(start.data_ptr() if total else 0),
+                                              C.c_void_p(end.data_ptr() if total else 0), _stream_ptr(stream)))
+        return count, first, start, end
 
     def match_extents(self, data, offsets, trim=0, out=None, stream=None):
         """item i = data[offsets[i] : offsets[i+1] - trim]; '\\n' is an ordinary character."""

@@ -432,13 +432,8 @@ int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accep
     return RRX_OK;
 }
 
-int rrx_search_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_start, uint32_t *d_end, void *stream) {
-    if (!re || !c || (c->nlines && (!d_start || !d_end))) return fail(RRX_ERR_ARG, "null argument");
-    const dev::SearchDevice *t;
-    int rc = re->search_tables(c->device, &t);
-    if (rc) return rc;
-    HIP_TRY(hipSetDevice(c->device));
-    if (!c->nlines) return RRX_OK;
+// per-line offsets of the corpus, built on the first search (cached in the corpus)
+static int line_offsets(const rrx_corpus *c, void *stream) {
     {
         std::lock_guard<std::mutex> lock(c->mu);
         if (!c->d_line_off) {
@@ -455,8 +450,48 @@ int rrx_search_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_star
             c->d_line_off = off;
         }
     }
+    return RRX_OK;
+}
+
+int rrx_search_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_start, uint32_t *d_end, void *stream) {
+    if (!re || !c || (c->nlines && (!d_start || !d_end))) return fail(RRX_ERR_ARG, "null argument");
+    const dev::SearchDevice *t;
+    int rc = re->search_tables(c->device, &t);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->nlines) return RRX_OK;
+    rc = line_offsets(c, stream);
+    if (rc) return rc;
     int e = dev::search_lines(*t, c->d_bytes, c->nbytes, c->d_line_off, c->nlines, d_start, d_end, stream);
     if (e) return hip_fail((hipError_t)e, "search_lines launch");
+    return RRX_OK;
+}
+
+int rrx_search_all_count(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_count, void *stream) {
+    if (!re || !c || (c->nlines && !d_count)) return fail(RRX_ERR_ARG, "null argument");
+    const dev::SearchDevice *t;
+    int rc = re->search_tables(c->device, &t);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->nlines) return RRX_OK;
+    rc = line_offsets(c, stream);
+    if (rc) return rc;
+    int e = dev::search_all(*t, c->d_bytes, c->nbytes, c->d_line_off, c->nlines, d_count, nullptr, nullptr, nullptr, stream);
+    if (e) return hip_fail((hipError_t)e, "search_all launch");
+    return RRX_OK;
+}
+
+int rrx_search_all_fill(const rrx_regex *re, const rrx_corpus *c, const uint64_t *d_first, uint32_t *d_start, uint32_t *d_end, void *stream) {
+    if (!re || !c || (c->nlines && (!d_first || !d_start || !d_end))) return fail(RRX_ERR_ARG, "null argument");
+    const dev::SearchDevice *t;
+    int rc = re->search_tables(c->device, &t);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    if (!c->nlines) return RRX_OK;
+    rc = line_offsets(c, stream);
+    if (rc) return rc;
+    int e = dev::search_all(*t, c->d_bytes, c->nbytes, c->d_line_off, c->nlines, nullptr, d_first, d_start, d_end, stream);
+    if (e) return hip_fail((hipError_t)e, "search_all launch");
     return RRX_OK;
 }
 

@@ -132,6 +132,10 @@ int build_line_offsets(const uint8_t *bytes, size_t nbytes, uint32_t stripe, con
 int search_lines(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *line_off, size_t nlines,
                  uint32_t *match_start, uint32_t *match_end, void *stream);
 
+// all matches per line: first == nullptr counts (count[i]); otherwise fills the slots first[i], first[i] + 1, ...
+int search_all(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *line_off, size_t nlines, uint32_t *count,
+               const uint64_t *first, uint32_t *match_start, uint32_t *match_end, void *stream);
+
 // One long string (regex.h:156-159 consumes it byte by byte): the string is cut into chunks, every chunk is stepped
 // from EVERY table state at once (lane = (chunk, start state); the lanes of a chunk read the same text), which yields
 // one state -> state map per chunk; maps are then composed in groups until one is left.  `scratch` holds the maps.

@@ -998,6 +998,39 @@ struct SearchTables {
         empty_matches = p.acc_f[p.start_f] != 0;
     }
 };
+// First match of bytes[p, b) whose start is >= p: false if there is none.  s, e are absolute offsets.
+__device__ __forceinline__ bool search_from(const SearchTables &t, const uint8_t *__restrict__ bytes, size_t nbytes, size_t p, size_t b,
+                                            size_t &s, size_t &e) {
+    if (t.empty_matches) { s = p; e = p; return true; }          // the pattern accepts "": the match is [p, p)
+    uint32_t q = t.start_f;
+    size_t pos = p;
+    bool found = false;
+    while (pos < b && !found) {                                   // aligned dwords; bytes before `pos` / from `b` on are skipped
+        const size_t base = pos & ~(size_t)3;
+        uint32_t w;
+        if (base + 4 <= nbytes) w = *reinterpret_cast<const uint32_t *>(bytes + base);
+        else { w = 0; for (size_t k = pos; k < nbytes; k++) w |= (uint32_t)bytes[k] << (8 * (k - base)); }     // last dword of the data
+        const size_t stop = base + 4 < b ? base + 4 : b;
+        for (; pos < stop; pos++) {
+            const uint32_t x = t.next_f[q * t.K + t.cls[(w >> (8 * (pos - base))) & 0xffu]];
+            q = x & 0x7fffu;
+            if (x & 0x8000u) { found = true; pos++; break; }
+        }
+    }
+    if (!found) return false;
+    e = pos;
+    uint32_t r = t.start_r;
+    size_t best = pos;
+    for (size_t k = pos; k > p;) {
+        k--;
+        const uint32_t x = t.next_r[r * t.K + t.cls[bytes[k]]];
+        r = x & 0x7fffu;
+        if (!r) break;                                            // state 0 is dead
+        if (x & 0x8000u) best = k;
+    }
+    s = best;
+    return true;
+}
 __global__ __launch_bounds__(256) void search_lines_kernel(SearchDevice prog, const uint8_t *__restrict__ bytes, size_t nbytes,
                                                            const uint64_t *__restrict__ line_off, size_t nlines,
                                                            uint32_t *__restrict__ match_start, uint32_t *__restrict__ match_end) {
@@ -1008,41 +1041,35 @@ __global__ __launch_bounds__(256) void search_lines_kernel(SearchDevice prog, co
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nlines) return;
     const size_t a = line_off[i], b = line_off[i + 1] - 1;        // [a, b): the line without its '\n'
-    uint32_t s = 0xffffffffu, e = 0xffffffffu;
-    if (t.empty_matches) {
-        s = 0; e = 0;                                             // the pattern accepts "": the match is [0, 0)
-    } else {
-        uint32_t q = t.start_f;
-        size_t pos = a;
-        bool found = false;
-        while (pos < b && !found) {                               // aligned dwords; bytes before `pos` / from `b` on are skipped
-            const size_t base = pos & ~(size_t)3;
-            uint32_t w;
-            if (base + 4 <= nbytes) w = *reinterpret_cast<const uint32_t *>(bytes + base);
-            else { w = 0; for (size_t k = pos; k < nbytes; k++) w |= (uint32_t)bytes[k] << (8 * (k - base)); }     // last dword of the data
-            const size_t stop = base + 4 < b ? base + 4 : b;
-            for (; pos < stop; pos++) {
-                const uint32_t x = t.next_f[q * t.K + t.cls[(w >> (8 * (pos - base))) & 0xffu]];
-                q = x & 0x7fffu;
-                if (x & 0x8000u) { found = true; pos++; break; }
-            }
-        }
-        if (found) {
-            e = (uint32_t)(pos - a);
-            uint32_t r = t.start_r;
-            size_t best = pos;
-            for (size_t k = pos; k > a;) {
-                k--;
-                const uint32_t x = t.next_r[r * t.K + t.cls[bytes[k]]];
-                r = x & 0x7fffu;
-                if (!r) break;                                    // state 0 is dead
-                if (x & 0x8000u) best = k;
-            }
-            s = (uint32_t)(best - a);
-        }
+    size_t s, e;
+    const bool found = search_from(t, bytes, nbytes, a, b, s, e);
+    match_start[i] = found ? (uint32_t)(s - a) : 0xffffffffu;
+    match_end[i] = found ? (uint32_t)(e - a) : 0xffffffffu;
+}
+// All matches of a line, left to right: after a match the search continues at its end (one byte further after an empty
+// match).  FILL = false: count[i] = number of matches.  FILL = true: the matches of line i go to slots first[i], ...
+template <bool FILL>
+__global__ __launch_bounds__(256) void search_all_kernel(SearchDevice prog, const uint8_t *__restrict__ bytes, size_t nbytes,
+                                                         const uint64_t *__restrict__ line_off, size_t nlines,
+                                                         uint32_t *__restrict__ count, const uint64_t *__restrict__ first,
+                                                         uint32_t *__restrict__ match_start, uint32_t *__restrict__ match_end) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    SearchTables t;
+    t.load(prog, smem);
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nlines) return;
+    const size_t a = line_off[i], b = line_off[i + 1] - 1;
+    uint64_t slot = FILL ? first[i] : 0;
+    uint32_t k = 0;
+    for (size_t p = a; p <= b;) {
+        size_t s, e;
+        if (!search_from(t, bytes, nbytes, p, b, s, e)) break;
+        if (FILL) { match_start[slot + k] = (uint32_t)(s - a); match_end[slot + k] = (uint32_t)(e - a); }
+        k++;
+        p = e > s ? e : e + 1;
     }
-    match_start[i] = s;
-    match_end[i] = e;
+    if (!FILL) count[i] = k;
 }
 
 // ============================================================================================ one long string
@@ -1206,6 +1233,20 @@ int search_lines(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, con
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(search_lines_kernel, dim3((unsigned)((nlines + 255) / 256)), dim3(256), lds, (hipStream_t)stream, p, bytes, nbytes, line_off, nlines,
                        match_start, match_end);
+    return (int)hipGetLastError();
+}
+int search_all(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *line_off, size_t nlines, uint32_t *count,
+               const uint64_t *first, uint32_t *match_start, uint32_t *match_end, void *stream) {
+    if (!nlines) return 0;
+    const size_t lds = search_lds_bytes(p);
+    if (lds > kSearchLdsBudget || p.nf > 32767 || p.nr > 32767) return (int)hipErrorInvalidValue;
+    const bool fill = first != nullptr;
+    hipError_t e = fill ? hipFuncSetAttribute(reinterpret_cast<const void *>(search_all_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
+                        : hipFuncSetAttribute(reinterpret_cast<const void *>(search_all_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    const dim3 grid((unsigned)((nlines + 255) / 256));
+    if (fill) hipLaunchKernelGGL(search_all_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, p, bytes, nbytes, line_off, nlines, count, first, match_start, match_end);
+    else hipLaunchKernelGGL(search_all_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, p, bytes, nbytes, line_off, nlines, count, first, match_start, match_end);
     return (int)hipGetLastError();
 }
 static uint32_t long_chunk(size_t nbytes) {

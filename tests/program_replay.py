@@ -92,17 +92,18 @@ class SearchReplay:
     def __init__(self, fwd_words, rev_words):
         self.f, self.r = DfaReplay(fwd_words), DfaReplay(rev_words)
 
-    def search(self, line):
+    def search(self, line, p=0):
+        """first match of line[p:] (offsets relative to the line), or (-1, -1)"""
         f, r = self.f, self.r
         q = f.start
         if f.acc[q]:
-            return 0, 0
-        for i, c in enumerate(line):
-            q = int(f.next[q, f.cls[c]])
+            return p, p
+        for i in range(p, len(line)):
+            q = int(f.next[q, f.cls[line[i]]])
             if f.acc[q]:
                 e = i + 1
                 s, st = e, r.start
-                for k in range(e - 1, -1, -1):
+                for k in range(e - 1, p - 1, -1):
                     st = int(r.next[st, r.cls[line[k]]])
                     if st == 0:
                         break
@@ -110,3 +111,14 @@ class SearchReplay:
                         s = k
                 return s, e
         return -1, -1
+
+    def search_all(self, line):
+        """all matches left to right: continue at the end of a match, one byte further after an empty one"""
+        out, p = [], 0
+        while p <= len(line):
+            s, e = self.search(line, p)
+            if e < 0:
+                break
+            out.append((s, e))
+            p = e if e > s else e + 1
+        return out

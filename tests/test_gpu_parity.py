@@ -467,3 +467,51 @@ def test_search_corpus_long_lines_across_stripes():
         ws = np.array([w[0] for w in want], dtype=np.int32)
         we = np.array([w[1] for w in want], dtype=np.int32)
         _check_search(p, data, ws, we, stripes=STRIPES)
+
+
+def test_search_all_matches_per_line():
+    """rrx_search_all_count / _fill: every lazy match of every line, left to right (after a match the search continues
+    at its end, one byte further after an empty match).  Short lines against the oracle's brute force, long lines
+    (matches on both sides of stripe boundaries) against the CPU replay of the two search tables."""
+    from program_replay import SearchReplay
+    rng = random.Random(13)
+    pats = ["ab+c", "a*", "a?", "(a|b)*abb", "[0-9]+", "x?y?z?", "k(1|10|100)", "a{2,4}b", "[^a]b", EMAIL]
+    while len(pats) < 26:
+        p = random_pattern(rng)
+        try:
+            if OracleRegex(p).states_n <= 120:
+                pats.append(p)
+        except OracleError:
+            pass
+
+    def run(pattern, data):
+        dev = torch.from_numpy(np.array(np.frombuffer(data, dtype=np.uint8), copy=True)).cuda()
+        r = rr.RRegex(pattern)
+        cnt, first, st, en = r.search_all(rr.Corpus(dev, stripe=1024))
+        return cnt.cpu().numpy(), first.cpu().numpy(), st.cpu().numpy(), en.cpu().numpy()
+
+    for p in pats:
+        o = OracleRegex(p)
+        alphabet = "abcxk01.d@yz" if p != EMAIL else "ab1.@"
+        lines = ["".join(rng.choice(alphabet) for _ in range(rng.choice([0, 0, 1, 2, 5, 9, 14, 22]))).encode() for _ in range(2500)]
+        for tail in (b"\n", b""):
+            data = b"\n".join(lines) + tail
+            wc, ws, we = o.search_all(data)
+            cnt, first, st, en = run(p, data)
+            assert (cnt == wc.astype(np.int32)).all(), p
+            assert (first == np.concatenate([[0], np.cumsum(wc)[:-1]])).all(), p
+            assert (st == ws).all() and (en == we).all(), p
+    for p in ("ab+c", "[0-9]+\\.[0-9]+"):
+        r = rr.RRegex(p)
+        rep = SearchReplay(r.program(rr.PROGRAM_SEARCH_FWD), r.program(rr.PROGRAM_SEARCH_REV))
+        needle = {"ab+c": b"abbbbc", "[0-9]+\\.[0-9]+": b"12345.678"}[p]
+        lines = []
+        for n in (0, 1, 1000, 1017, 1024, 2048, 3000, 4096, 9000):
+            filler = bytes(rng.choice(b"xyz ") for _ in range(n))
+            lines += [filler + needle + filler + needle + b" tail " + needle, filler, needle * 3 + filler]
+        data = b"\n".join(lines)
+        cnt, first, st, en = run(p, data)
+        for i, ln in enumerate(lines):
+            want = rep.search_all(ln)
+            got = [(int(st[first[i] + j]), int(en[first[i] + j])) for j in range(int(cnt[i]))]
+            assert got == want, (p, i, len(ln), got[:3], want[:3])

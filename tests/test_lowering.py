@@ -268,3 +268,9 @@ def test_search_tables_find_the_earliest_ending_leftmost_match():
         st, en = o.search_lines(b"\n".join(lines) + b"\n")
         for ln, s, e in zip(lines, st, en):
             assert rep.search(ln) == (int(s), int(e)), (p[:50], ln, (int(s), int(e)))
+        cnt, ast, aen = o.search_all(b"\n".join(lines) + b"\n")
+        k = 0
+        for ln, c in zip(lines, cnt):
+            want = [(int(ast[k + j]), int(aen[k + j])) for j in range(int(c))]
+            assert rep.search_all(ln) == want, (p[:50], ln, want)
+            k += int(c)
