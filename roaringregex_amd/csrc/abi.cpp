@@ -395,6 +395,18 @@ int rrx_corpus_create_ex(int device, const void *d_bytes, size_t nbytes, uint32_
     if (e != hipSuccess) { rrx_corpus_free(c); return hip_fail(e, "line index readback"); }
     c->has_high = (flags & 1u) != 0;
     c->nlines = (size_t)total + ((nbytes && last != '\n') ? 1 : 0);
+    // The size-based stripe suits lines of a few dozen bytes.  Every lane walks half a line past its stripe, so long
+    // lines want longer stripes (a{1,300} config, 200 B per line, 1 GiB: 4 KiB stripes +14 % over 2 KiB): with the
+    // line count known, double the stripe while a line is more than 1/16 of it, and index once more.
+    if (!stripe_bytes && c->nlines) {
+        const size_t avg_line = nbytes / c->nlines;
+        uint32_t want = c->stripe;
+        while (want < dev::kMaxStripe && avg_line * 16 > want && nbytes / (2 * (size_t)want) >= ((size_t)1 << 17)) want *= 2;
+        if (want != c->stripe) {
+            rrx_corpus_free(c);
+            return rrx_corpus_create_ex(device, d_bytes, nbytes, want, stream, out);
+        }
+    }
     *out = c;
     return RRX_OK;
 }
