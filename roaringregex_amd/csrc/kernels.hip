@@ -296,7 +296,9 @@ struct PlainDfaEngine {
     __device__ __forceinline__ void step(State &st, uint32_t c) const { st.s = next[st.s * ncls + cls[c]]; }
 };
 
-// Text is read once: a streaming (non-temporal) load keeps it from displacing the accept bitmap's lines in L2.
+// Text loads.  RRX_TEXT_NT=1 (measurement only) makes them non-temporal: the idea was to keep the streamed text from
+// displacing the accept bitmap's lines in L2, the effect is that the 8 loads of a 128-byte line no longer merge into
+// one request (-47 %).  The result window in LDS solved the bitmap problem instead.
 #ifndef RRX_TEXT_NT
 #define RRX_TEXT_NT 0
 #endif
