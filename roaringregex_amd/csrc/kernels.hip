@@ -296,6 +296,10 @@ struct PlainDfaEngine {
     __device__ __forceinline__ void step(State &st, uint32_t c) const { st.s = next[st.s * ncls + cls[c]]; }
 };
 
+constexpr uint32_t kEndsOnNewline = 0x80000000u;         // bit 31 of counts[k]: stripe k ends on a '\n'
+constexpr uint64_t kFreshStripe = 1ull << 63;             // bit 63 of stripe_base[k]: stripe k begins at the start of a line
+__device__ __forceinline__ uint64_t line_of(uint64_t base) { return base & ~kFreshStripe; }
+
 // Text loads.  RRX_TEXT_NT=1 (measurement only) makes them non-temporal: the idea was to keep the streamed text from
 // displacing the accept bitmap's lines in L2, the effect is that the 8 loads of a 128-byte line no longer merge into
 // one request (-47 %).  The result window in LDS solved the bitmap problem instead.
@@ -401,17 +405,18 @@ __global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, c
     __syncthreads();
 
     const size_t g0 = (size_t)blockIdx.x * kThreads;
-    const uint64_t window_word = stripe_base[g0] >> 5;               // the workgroup's first stripe exists: uniform load
+    const uint64_t window_word = line_of(stripe_base[g0]) >> 5;      // the workgroup's first stripe exists: uniform load
     const size_t g = g0 + threadIdx.x;
     const size_t start = g * (size_t)stripe;
     if (start < nbytes) {                                            // (no early return: the write-out below is collective)
     const size_t stripe_end = start + stripe;
     const size_t my_end = stripe_end < nbytes ? stripe_end : nbytes;
-    const bool fresh = start == 0 || bytes[start - 1] == '\n';
+    const uint64_t my_base = stripe_base[g];
+    const bool fresh = (my_base & kFreshStripe) != 0;
     typename Engine::State st = fresh ? eng.fresh() : eng.skipping();
     ResultsT<Engine::kStaged> res;
-    if (Engine::kStaged) res.begin_staged(stripe_base[g], window_word, !fresh, accept_bits, stage);
-    else res.begin(stripe_base[g], !fresh, accept_bits);
+    if (Engine::kStaged) res.begin_staged(line_of(my_base), window_word, !fresh, accept_bits, stage);
+    else res.begin(line_of(my_base), !fresh, accept_bits);
 
     // ---- main phase: whole 128-byte rounds of my stripe.  The 8 loads of a line are issued as ONE burst after the
     // previous line has been consumed (they merge on one L2 request; other waves of the SIMD cover the fetch).
@@ -581,16 +586,17 @@ __global__ __launch_bounds__(kThreads) void match_stripes2_kernel(Dfa2Device pro
     __syncthreads();
 
     const size_t g0 = (size_t)blockIdx.x * kThreads;
-    const uint64_t window_word = stripe_base[g0] >> 5;               // the workgroup's first stripe exists: uniform load
+    const uint64_t window_word = line_of(stripe_base[g0]) >> 5;      // the workgroup's first stripe exists: uniform load
     const size_t g = g0 + threadIdx.x;
     const size_t start = g * (size_t)stripe;
     if (start < nbytes) {                                            // (no early return: the write-out below is collective)
     const size_t stripe_end = start + stripe;
     const size_t my_end = stripe_end < nbytes ? stripe_end : nbytes;
-    const bool fresh = start == 0 || bytes[start - 1] == '\n';
+    const uint64_t my_base = stripe_base[g];
+    const bool fresh = (my_base & kFreshStripe) != 0;
     Dfa2::State st = fresh ? eng.fresh() : eng.skipping();
     ResultsT<true> res;
-    res.begin_staged(stripe_base[g], window_word, !fresh, accept_bits, lds.stage);
+    res.begin_staged(line_of(my_base), window_word, !fresh, accept_bits, lds.stage);
 
     size_t pos = start;
     const uint4 *src = reinterpret_cast<const uint4 *>(bytes + start);
@@ -728,10 +734,11 @@ __global__ __launch_bounds__(256) void match_stripes_wave_kernel(WaveNfaDevice p
     if (start >= nbytes) return;
     const size_t stripe_end = start + stripe;
     const size_t my_end = stripe_end < nbytes ? stripe_end : nbytes;
-    const bool fresh = start == 0 || bytes[start - 1] == '\n';
+    const uint64_t my_base = stripe_base[g];
+    const bool fresh = (my_base & kFreshStripe) != 0;
     uint32_t s0 = fresh ? eng.init[0] : 0, s1 = fresh ? eng.init[1] : 0;   // not fresh: dead until the first '\n'
     Results res;
-    res.begin(stripe_base[g], !fresh, accept_bits);
+    res.begin(line_of(my_base), !fresh, accept_bits);
     res.writer = lane == 0;
 
     // ---- the lines inside my stripe, 64 bytes of text per turn (one per lane, broadcast with readlane)
@@ -864,7 +871,9 @@ __global__ __launch_bounds__(256) void count_newlines_kernel(const uint8_t *__re
         }
     }
     for (size_t p = start + (size_t)u * 16; p < end; p++) { cnt += bytes[p] == '\n'; high |= bytes[p]; }
-    counts[g] = cnt;
+    // bit 31: the stripe ends on a '\n', i.e. the next stripe starts a fresh line (the scan moves it to bit 63 of
+    // that stripe's base, so the match kernels need not probe the byte before their stripe)
+    counts[g] = cnt | (bytes[end - 1] == '\n' ? kEndsOnNewline : 0u);
     if (high & 0x80808080u) atomicOr(flags, 1u);
 }
 
@@ -895,7 +904,7 @@ __global__ __launch_bounds__(256) void scan_chunk_sums_kernel(const uint32_t *__
     __shared__ uint64_t part[4];
     const size_t lo = (size_t)blockIdx.x * kScanChunk;
     uint64_t s = 0;
-    for (size_t i = lo + threadIdx.x; i < lo + kScanChunk && i < n; i += 256) s += counts[i];
+    for (size_t i = lo + threadIdx.x; i < lo + kScanChunk && i < n; i += 256) s += counts[i] & ~kEndsOnNewline;
 #pragma unroll
     for (int d = 32; d; d >>= 1) s += __shfl_down(s, d, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
@@ -924,7 +933,7 @@ __global__ __launch_bounds__(256) void scan_chunks_kernel(const uint32_t *__rest
     __shared__ uint64_t sh[256];
     const size_t lo = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * (kScanChunk / 256);
     uint64_t s = 0;
-    for (size_t i = lo; i < lo + kScanChunk / 256 && i < n; i++) s += counts[i];
+    for (size_t i = lo; i < lo + kScanChunk / 256 && i < n; i++) s += counts[i] & ~kEndsOnNewline;
     sh[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -933,7 +942,11 @@ __global__ __launch_bounds__(256) void scan_chunks_kernel(const uint32_t *__rest
     }
     __syncthreads();
     uint64_t run = sh[threadIdx.x];
-    for (size_t i = lo; i < lo + kScanChunk / 256 && i < n; i++) { base[i] = run; run += counts[i]; }
+    for (size_t i = lo; i < lo + kScanChunk / 256 && i < n; i++) {
+        const bool fresh = i == 0 || (counts[i - 1] & kEndsOnNewline);
+        base[i] = run | (fresh ? kFreshStripe : 0);
+        run += counts[i] & ~kEndsOnNewline;
+    }
 }
 
 template <class Engine, class Program>
@@ -963,7 +976,7 @@ __global__ __launch_bounds__(256) void line_offsets_kernel(const uint8_t *__rest
     const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= nstripes) return;
     const size_t start = g * (size_t)stripe, end = start + stripe < nbytes ? start + stripe : nbytes;
-    uint64_t line = stripe_base[g];                      // index of the line that contains my first byte
+    uint64_t line = line_of(stripe_base[g]);             // index of the line that contains my first byte
     if (g == 0) line_off[0] = 0;
     size_t pos = start;
     for (; pos + 16 <= end; pos += 16) {                 // stripes start 16-byte aligned
