@@ -50,9 +50,9 @@ def measured_traffic(workload, nbytes, engine_name):
     """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE in
     separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, the factor re-checked on
     our own access pattern with the pure-streaming newline-count kernel).  Only quoted for the exact
-    configuration that was profiled: profiles/r01_v7_staged_url_8GiB_rocprofv3_summary.txt."""
+    configuration that was profiled: profiles/r01_v8_final_url_8GiB_rocprofv3_summary.txt."""
     if workload == "url" and nbytes == 8 << 30 and engine_name == "dfa-stride2-table":
-        fetch_kb, write_kb = 4.58851e6, 24370.2
+        fetch_kb, write_kb = 4.45964e6, 24370.2
         return int(fetch_kb * 1024 * 2 + write_kb * 1024)
     return None
 
