@@ -279,7 +279,7 @@ int rrx_compile_ex(const char *pattern, int engine, rrx_regex **out) {
                 // stride-2 form: when the table (rows of distinct pair columns) fits next to the 32 KiB pair table
                 if (re->has_dfa && !re->line_global && engine != RRX_ENGINE_DFA && re->dfa.nstates <= 4096) {
                     re->has_dfa2 = lower_dfa2(re->dfa, 1024, re->dfa2) &&
-                                   (size_t)re->dfa2.nstates * (re->dfa2.ncols | 1u) * 4 <= dev::kDfa2TableBudget;
+                                   (size_t)re->dfa2.nstates * (re->dfa2.ncols | 1u) * 4 <= dev::kDfa2MaxTable;
                 }
             }
         }

@@ -90,7 +90,11 @@ struct Dfa2Device {
 };
 constexpr uint32_t kDfa2PStride = 130;                // u16 entries per P row
 constexpr uint32_t kDfa2PBytes = 128 * kDfa2PStride * 2;
-constexpr uint32_t kDfa2TableBudget = 30 * 1024;     // T2 + P (32.5 KiB) + 16 KiB result window = 78.5 KiB: two 1024-lane workgroups per 160-KiB CU
+// LDS of a stride-2 workgroup: P (32.5 KiB) + one 46 KiB region shared by T2 and the result window = 78.5 KiB, i.e. two
+// 1024-lane workgroups per 160-KiB CU.  Copies of T2 are only made while they leave the window its 16 KiB.
+constexpr uint32_t kDfa2RegionBytes = 46 * 1024;
+constexpr uint32_t kDfa2MaxTable = kDfa2RegionBytes - 4 * 1024;       // a table this large leaves a 4 KiB window
+constexpr uint32_t kDfa2TableBudget = 30 * 1024;                      // T2 with its copies
 
 int match_stripes_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
                        size_t nstripes, uint32_t *accept_bits, void *stream);

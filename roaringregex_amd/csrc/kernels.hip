@@ -339,6 +339,7 @@ struct ResultsT {
     bool writer = true;                    // wave-cooperative kernels: every lane mirrors the bookkeeping, one writes
     uint32_t *__restrict__ out;            // STAGED: already advanced to the first word of the window
     uint32_t *stage = nullptr;
+    uint32_t stage_words = kStageWords;    // words of the window
 
     __device__ __forceinline__ void begin(uint64_t first_line, bool drop, uint32_t *bitmap) {
         word = first_line >> 5; fill = (uint32_t)first_line & 31u; drop_first = drop; out = bitmap;
@@ -349,7 +350,7 @@ struct ResultsT {
     }
     __device__ __forceinline__ void emit() {
         if (!outw || !writer) return;
-        if (STAGED && word < kStageWords) atomicOr(&stage[(uint32_t)word], outw);
+        if (STAGED && word < stage_words) atomicOr(&stage[(uint32_t)word], outw);
         else
 #if defined(RRX_PROBE_FLUSH_STORE)      /* measurement only: plain store instead of the atomic (wrong at shared words) */
             out[word] = outw;
@@ -504,7 +505,7 @@ struct Dfa2 {
     const uint16_t *P;                     // LDS (a static array at a link-time address: no base to add per pair)
     uint32_t start_off, dead_off;
 
-    static size_t lds_bytes(const Dfa2Device &p) { return (size_t)p.nrows * p.stride * 4; }     // dynamic part: T2
+    __host__ __device__ static size_t lds_bytes(const Dfa2Device &p) { return (size_t)p.nrows * p.stride * 4; }     // dynamic part: T2
     __device__ void load(const Dfa2Device &p, uint16_t *p_lds, uint8_t *t_lds) {
         uint32_t *pl = reinterpret_cast<uint32_t *>(p_lds);
         const uint32_t *ps = reinterpret_cast<const uint32_t *>(p.P);
@@ -574,15 +575,18 @@ struct Dfa2 {
 __global__ __launch_bounds__(kThreads) void match_stripes2_kernel(Dfa2Device prog, const uint8_t *__restrict__ bytes, size_t nbytes,
                                                                    uint32_t stripe, const uint64_t *__restrict__ stripe_base,
                                                                    uint32_t *__restrict__ accept_bits) {
-    // T2 first: its entries hold 16-bit LDS addresses.  All arrays are static, so every base is a link-time constant.
+    // T2 first: its entries hold 16-bit LDS addresses; the result window takes what T2 leaves of its region (16 KiB and
+    // more for tables up to 30 KiB, 4 KiB at least).  The arrays are static, so P's base is a link-time constant.
     __shared__ __attribute__((aligned(16))) struct {
-        uint8_t t2[kDfa2TableBudget];
+        uint8_t t2_and_stage[kDfa2RegionBytes];
         uint16_t p[kDfa2PBytes / 2];
-        uint32_t stage[kStageWords];
     } lds;
     Dfa2 eng;
-    eng.load(prog, lds.p, lds.t2);
-    for (uint32_t i = threadIdx.x; i < kStageWords; i += kThreads) lds.stage[i] = 0;
+    eng.load(prog, lds.p, lds.t2_and_stage);
+    const uint32_t stage_off = (uint32_t)((Dfa2::lds_bytes(prog) + 15) & ~(size_t)15);
+    uint32_t *const stage = reinterpret_cast<uint32_t *>(lds.t2_and_stage + stage_off);
+    const uint32_t stage_words = (kDfa2RegionBytes - stage_off) / 4;
+    for (uint32_t i = threadIdx.x; i < stage_words; i += kThreads) stage[i] = 0;
     __syncthreads();
 
     const size_t g0 = (size_t)blockIdx.x * kThreads;
@@ -596,7 +600,8 @@ __global__ __launch_bounds__(kThreads) void match_stripes2_kernel(Dfa2Device pro
     const bool fresh = (my_base & kFreshStripe) != 0;
     Dfa2::State st = fresh ? eng.fresh() : eng.skipping();
     ResultsT<true> res;
-    res.begin_staged(line_of(my_base), window_word, !fresh, accept_bits, lds.stage);
+    res.begin_staged(line_of(my_base), window_word, !fresh, accept_bits, stage);
+    res.stage_words = stage_words;
 
     size_t pos = start;
     const uint4 *src = reinterpret_cast<const uint4 *>(bytes + start);
@@ -666,8 +671,8 @@ __global__ __launch_bounds__(kThreads) void match_stripes2_kernel(Dfa2Device pro
     // ---- write the window out: consecutive lanes, consecutive words (the atomics merge into whole lines in L2;
     // the first and the last word of the window are shared with the neighbouring workgroups)
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < kStageWords; i += kThreads) {
-        const uint32_t v = lds.stage[i];
+    for (uint32_t i = threadIdx.x; i < stage_words; i += kThreads) {
+        const uint32_t v = stage[i];
         if (v) atomicOr(&accept_bits[window_word + i], v);
     }
 }
@@ -1220,7 +1225,7 @@ int match_extents_wave_nfa(const WaveNfaDevice &p, const uint8_t *bytes, const u
 int match_stripes_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
                        size_t nstripes, uint32_t *accept, void *stream) {
     if (!nstripes) return 0;
-    if (Dfa2::lds_bytes(p) > kDfa2TableBudget) return (int)hipErrorInvalidValue;
+    if (Dfa2::lds_bytes(p) > kDfa2MaxTable) return (int)hipErrorInvalidValue;
     size_t blocks = (nstripes + kThreads - 1) / kThreads;
     hipLaunchKernelGGL(match_stripes2_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept);
     return (int)hipGetLastError();
