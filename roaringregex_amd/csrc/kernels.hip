@@ -395,14 +395,15 @@ typedef ResultsT<false> Results;
 template <class Engine, class Program>
 __global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, const uint8_t *__restrict__ bytes, size_t nbytes,
                                                                   uint32_t stripe, const uint64_t *__restrict__ stripe_base,
-                                                                  uint32_t *__restrict__ accept_bits, uint32_t stage_off) {
+                                                                  uint32_t *__restrict__ accept_bits, uint32_t stage_off,
+                                                                  uint32_t stage_words) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // result window of the workgroup (ResultsT<true>), behind the tables: their entries hold 16-bit LDS addresses
     uint32_t *stage = reinterpret_cast<uint32_t *>(smem + stage_off);
     Engine eng;
     eng.load(prog, smem);
     if (Engine::kStaged)
-        for (uint32_t i = threadIdx.x; i < kStageWords; i += kThreads) stage[i] = 0;
+        for (uint32_t i = threadIdx.x; i < stage_words; i += kThreads) stage[i] = 0;
     __syncthreads();
 
     const size_t g0 = (size_t)blockIdx.x * kThreads;
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, c
     const bool fresh = (my_base & kFreshStripe) != 0;
     typename Engine::State st = fresh ? eng.fresh() : eng.skipping();
     ResultsT<Engine::kStaged> res;
-    if (Engine::kStaged) res.begin_staged(line_of(my_base), window_word, !fresh, accept_bits, stage);
+    if (Engine::kStaged) { res.begin_staged(line_of(my_base), window_word, !fresh, accept_bits, stage); res.stage_words = stage_words; }
     else res.begin(line_of(my_base), !fresh, accept_bits);
 
     // ---- main phase: whole 128-byte rounds of my stripe.  The 8 loads of a line are issued as ONE burst after the
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, c
     }
     if (Engine::kStaged) {
         __syncthreads();                             // write the window out: consecutive lanes, consecutive words
-        for (uint32_t i = threadIdx.x; i < kStageWords; i += kThreads) {
+        for (uint32_t i = threadIdx.x; i < stage_words; i += kThreads) {
             const uint32_t v = stage[i];
             if (v) atomicOr(&accept_bits[window_word + i], v);
         }
@@ -960,11 +961,14 @@ int launch_stripes(const Program &p, size_t table_bytes, const uint8_t *bytes, s
     if (!nstripes) return 0;
     auto k = match_stripes_kernel<Engine, Program>;
     const uint32_t stage_off = (uint32_t)((table_bytes + 15) & ~(size_t)15);
-    const size_t lds = Engine::kStaged ? stage_off + kStageWords * sizeof(uint32_t) : table_bytes;
+    // the window takes what the tables leave of half a CU's LDS (two workgroups per CU), 16 KiB at least
+    const size_t half_cu = 80 * 1024;
+    const uint32_t stage_words = stage_off + kStageWords * sizeof(uint32_t) >= half_cu ? kStageWords : (uint32_t)((half_cu - stage_off) / 4);
+    const size_t lds = Engine::kStaged ? stage_off + (size_t)stage_words * sizeof(uint32_t) : table_bytes;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     size_t blocks = (nstripes + kThreads - 1) / kThreads;
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept, stage_off);
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept, stage_off, stage_words);
     return (int)hipGetLastError();
 }
 
