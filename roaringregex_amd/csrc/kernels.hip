@@ -39,6 +39,7 @@ namespace {
 template <bool WIDE, bool CLAMP>
 struct LineDfaEngine {
     static constexpr bool kStaged = true;      // results go through the workgroup's LDS window (ResultsT<true>)
+    static constexpr bool kEightWaves = false;
     // Table entry: bits 0..15 = byte offset of the next row, byte 2 = 1 iff the consumed byte was '\n',
     // byte 3 = verdict of the line it ended.  (16-bit entries read with ds_read_u16 measured 3-4 % slower.)
     struct State { uint32_t e; };
@@ -132,6 +133,7 @@ struct LineDfaEngine {
 // ---- table DFA whose table stays in global memory (L2-resident): any automaton up to 65535 interned sets ----
 struct LineDfaGlobalEngine {
     static constexpr bool kStaged = true;
+    static constexpr bool kEightWaves = false;
     struct State { uint32_t e; };          // low 24 bits = index of the current row's first entry
     const uint32_t *__restrict__ tab;      // HBM / L2
     const uint8_t *cls;                    // LDS [256]
@@ -222,6 +224,7 @@ struct NfaCore {
 template <int W>
 struct LineNfaEngine : NfaCore<W> {
     static constexpr bool kStaged = false;     // measured 10 % slower with the window (register pressure)
+    static constexpr bool kEightWaves = true;
     using State = typename NfaCore<W>::State;
     __device__ __forceinline__ State fresh() const {
         State st;
@@ -393,10 +396,9 @@ struct ResultsT {
 typedef ResultsT<false> Results;
 
 template <class Engine, class Program>
-__global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, const uint8_t *__restrict__ bytes, size_t nbytes,
-                                                                  uint32_t stripe, const uint64_t *__restrict__ stripe_base,
-                                                                  uint32_t *__restrict__ accept_bits, uint32_t stage_off,
-                                                                  uint32_t stage_words) {
+__device__ __forceinline__ void match_stripes_body(const Program &prog, const uint8_t *__restrict__ bytes, size_t nbytes,
+                                                   uint32_t stripe, const uint64_t *__restrict__ stripe_base,
+                                                   uint32_t *__restrict__ accept_bits, uint32_t stage_off, uint32_t stage_words) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // result window of the workgroup (ResultsT<true>), behind the tables: their entries hold 16-bit LDS addresses
     uint32_t *stage = reinterpret_cast<uint32_t *>(smem + stage_off);
@@ -814,6 +816,23 @@ __global__ __launch_bounds__(256) void match_extents_wave_kernel(WaveNfaDevice p
 // ============================================================================================ extents kernel
 // One lane per item; bytes come straight from HBM/L2.  Used for explicit (offset,len) batches, for the
 // iterator facade's single strings, and wherever '\n' is an ordinary character.
+// Two entry points for one body.  The table engines run best as the compiler allocates them (66 VGPRs; capping them at 64
+// for a second workgroup per CU measured -6 %); the register-resident NFA engines gain from the cap (+2 ... +13 %,
+// W >= 2 spills a little to scratch).
+template <class Engine, class Program>
+__global__ __launch_bounds__(kThreads) void match_stripes_kernel(Program prog, const uint8_t *__restrict__ bytes, size_t nbytes,
+                                                                  uint32_t stripe, const uint64_t *__restrict__ stripe_base,
+                                                                  uint32_t *__restrict__ accept_bits, uint32_t stage_off,
+                                                                  uint32_t stage_words) {
+    match_stripes_body<Engine, Program>(prog, bytes, nbytes, stripe, stripe_base, accept_bits, stage_off, stage_words);
+}
+template <class Engine, class Program>
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(8, 8)))
+void match_stripes_kernel_8waves(Program prog, const uint8_t *__restrict__ bytes, size_t nbytes, uint32_t stripe,
+                                 const uint64_t *__restrict__ stripe_base, uint32_t *__restrict__ accept_bits, uint32_t stage_off,
+                                 uint32_t stage_words) {
+    match_stripes_body<Engine, Program>(prog, bytes, nbytes, stripe, stripe_base, accept_bits, stage_off, stage_words);
+}
 template <class Engine, class Program>
 __global__ __launch_bounds__(kThreads) void match_extents_kernel(Program prog, const uint8_t *__restrict__ bytes,
                                                                   const uint64_t *__restrict__ off, size_t nitems, uint32_t trim,
@@ -959,7 +978,7 @@ template <class Engine, class Program>
 int launch_stripes(const Program &p, size_t table_bytes, const uint8_t *bytes, size_t nbytes, uint32_t stripe,
                    const uint64_t *stripe_base, size_t nstripes, uint32_t *accept, void *stream) {
     if (!nstripes) return 0;
-    auto k = match_stripes_kernel<Engine, Program>;
+    auto k = Engine::kEightWaves ? match_stripes_kernel_8waves<Engine, Program> : match_stripes_kernel<Engine, Program>;
     const uint32_t stage_off = (uint32_t)((table_bytes + 15) & ~(size_t)15);
     // the window takes what the tables leave of half a CU's LDS (two workgroups per CU), 16 KiB at least
     const size_t half_cu = 80 * 1024;
