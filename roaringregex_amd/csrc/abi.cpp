@@ -213,7 +213,10 @@ struct rrx_regex {
             t.line.in_global = line_global ? 1 : 0;
         }
         HIP_TRY(hipMalloc(&t.blob, host.size() + 16));
-        HIP_TRY(hipMemcpy(t.blob, host.data(), host.size(), hipMemcpyHostToDevice));
+        {
+            const hipError_t up = hipMemcpy(t.blob, host.data(), host.size(), hipMemcpyHostToDevice);
+            if (up != hipSuccess) { (void)hipFree(t.blob); return hip_fail(up, "device program upload"); }
+        }
         const uint8_t *base = static_cast<const uint8_t *>(t.blob);
         if (engine == RRX_ENGINE_NFA_WAVE) {
             t.wave.masks = reinterpret_cast<const uint32_t *>(base + oM);
