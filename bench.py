@@ -2,6 +2,7 @@
 """bench.py — GB/s of input scanned by the RoaringRegex hot path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 10 --warmup 2
+    python bench.py --gpus N ...          # N > 1 without WORLD_SIZE: starts the N ranks itself (child processes)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
            bench.py --gpus N --steps K --warmup W
 
@@ -39,6 +40,10 @@ WORKLOADS = {
 }
 
 
+ENGINES = {"auto": "ENGINE_AUTO", "nfa": "ENGINE_NFA", "dfa": "ENGINE_DFA", "dfa2": "ENGINE_DFA2", "wave": "ENGINE_NFA_WAVE",
+           "dfa-global": "ENGINE_DFA_GLOBAL"}
+
+
 def patterns():
     with open(os.path.join(ROOT, "tests", "golden", "kat.json")) as f:
         kat = json.load(f)
@@ -47,15 +52,38 @@ def patterns():
     return {"U2": u2, "EMAIL": r"[A-Za-z0-9._]+@[A-Za-z0-9.]+", "A300": "a{1,300}", "K1000": k1000, "K1000C": ".*(" + k1000 + ").*"}
 
 
-def measured_traffic(workload, nbytes, engine_name):
-    """HBM bytes per launch from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and WRITE_SIZE in
-    separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, the factor re-checked on
-    our own access pattern with the pure-streaming newline-count kernel).  Only quoted for the exact
-    configuration that was profiled: profiles/r01_v8_final_url_8GiB_rocprofv3_summary.txt."""
-    if workload == "url" and nbytes == 8 << 30 and engine_name == "dfa-stride2-table":
-        fetch_kb, write_kb = 4.45964e6, 24370.2
-        return int(fetch_kb * 1024 * 2 + write_kb * 1024)
+def traffic_from_profile(workload, nbytes, engine_name):
+    """HBM bytes per launch as counted by an EARLIER rocprofv3 PMC run committed under profiles/ (FETCH_SIZE and
+    WRITE_SIZE in separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).  bench.py cannot
+    read PMC counters itself, so `roofline.traffic` (= measured in this run) stays null and this figure is reported
+    beside it, with the file it comes from, only for the exact configuration that was profiled."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return None
+    for row in table:
+        if row["workload"] == workload and row["bytes"] == nbytes and row["engine"] == engine_name:
+            return {"bytes": int(row["fetch_kb"] * 1024 * 2 + row["write_kb"] * 1024), "file": row["file"], "kernel": row.get("kernel")}
     return None
+
+
+def launch_ranks(n, argv):
+    """`bench.py --gpus N` with no WORLD_SIZE in the environment: start the N ranks as CHILD processes (one
+    torch.distributed.run, which starts one process per GPU) and relay their exit code.  This runs before torch is
+    imported and before anything touches the GPU in this process; nothing is exec'ed."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % n, "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
 
 
 def host_cores():
@@ -116,18 +144,45 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="url", choices=sorted(WORKLOADS))
     ap.add_argument("--bytes", type=int, default=0, help="bytes per GPU (default: the BASELINE size)")
-    ap.add_argument("--engine", default="auto", choices=["auto", "nfa", "dfa", "dfa2"])
+    ap.add_argument("--engine", default="auto", choices=sorted(ENGINES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stripe", type=int, default=0, help="bytes per GPU lane (0 = chosen from the corpus size)")
     ap.add_argument("--pcie", action="store_true", help="also time the host-buffer entry (upload + index + match + download)")
     ap.add_argument("--search", action="store_true", help="also time rrx_search_corpus (match offsets per line) on the same corpus")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    # N > 1 and nobody started the ranks for us: do it ourselves, as child processes, before any GPU call here.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: the launch and the flag disagree" % (args.gpus, world))
+
+    # RRX_BENCH_REHEARSAL=1: all ranks share GPU 0 and talk over gloo — a dry run of the N > 1 control flow on a
+    # one-GPU box (numbers from it mean nothing).  RRX_BENCH_REHEARSAL=launcher: no device work at all — only the
+    # launcher, the rendezvous and the rank proof run (CPU test of the control flow; "value" is null).
+    rehearsal = os.environ.get("RRX_BENCH_REHEARSAL", "")
+    if rehearsal == "launcher":
+        import torch
+        import torch.distributed as dist
+        ranks_seen = 1
+        if world > 1:
+            dist.init_process_group("gloo")
+            t = torch.ones(1, dtype=torch.int64)
+            dist.all_reduce(t)
+            ranks_seen = int(t.item())
+            dist.destroy_process_group()
+        if ranks_seen != args.gpus:
+            raise SystemExit("rank proof failed: %d ranks answered, --gpus %d" % (ranks_seen, args.gpus))
+        if rank == 0:
+            print(json.dumps({"metric": "GB/s input scanned (whole job)", "value": None, "unit": "GB/s", "n_gpus": world,
+                              "ranks_seen": ranks_seen, "steps": args.steps, "warmup": args.warmup, "rehearsal": "launcher-only"}), flush=True)
+        return
 
     import numpy as np
     import torch
@@ -135,25 +190,28 @@ def main():
     import synth
 
     assert torch.cuda.is_available(), "bench.py needs a MI355X"
-    # RRX_BENCH_REHEARSAL=1: all ranks share GPU 0 and talk over gloo — a dry run of the N > 1 control flow on a
-    # one-GPU box (numbers from it mean nothing).  Normal runs: one rank per GPU, RCCL.
-    rehearsal = os.environ.get("RRX_BENCH_REHEARSAL") == "1"
-    if rehearsal:
+    if rehearsal == "1":
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
-        if rehearsal:
+        if rehearsal == "1":
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # rank proof: an all-reduce of ones over the process group that will also carry the barrier (RCCL on a real run)
+        t = torch.ones(1, dtype=torch.int64, device="cpu" if rehearsal == "1" else "cuda")
+        dist.all_reduce(t)
+        ranks_seen = int(t.item())
+        if ranks_seen != args.gpus:
+            raise SystemExit("rank proof failed: %d ranks answered, --gpus %d" % (ranks_seen, args.gpus))
 
     kind, pkey, default_bytes, config_name = WORKLOADS[args.workload]
     nbytes = args.bytes or default_bytes
     pattern = patterns()[pkey]
-    engine = {"auto": rr.ENGINE_AUTO, "nfa": rr.ENGINE_NFA, "dfa": rr.ENGINE_DFA, "dfa2": rr.ENGINE_DFA2}[args.engine]
-    regex = rr.RRegex(pattern, engine, device=local_rank)
+    regex = rr.RRegex(pattern, getattr(rr, ENGINES[args.engine]), device=local_rank)
 
     # ---- synthetic shard of this rank (seed differs per rank), generated on the host cores, then resident in HBM
     t0 = time.perf_counter()
@@ -183,6 +241,19 @@ def main():
     for _ in range(8):
         regex.match_corpus_bits(corpus, out=out)
     torch.cuda.synchronize()
+    # one-shot ("cold") rate: a corpus nobody has indexed yet — index build + one match, clocks warm, HIP events
+    e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+    cold = []
+    for _ in range(3):
+        e0.record()
+        c2 = rr.Corpus(dev, stripe=corpus.stripe)
+        e1.record()
+        regex.match_corpus_bits(c2, out=out)
+        e2.record()
+        torch.cuda.synchronize()
+        cold.append((e0.elapsed_time(e1), e1.elapsed_time(e2)))
+        del c2
+    cold_index_ms, cold_match_ms = min(cold, key=lambda p: p[0] + p[1])
     for _ in range(args.warmup):
         regex.match_corpus_bits(corpus, out=out)
     barrier()
@@ -194,22 +265,30 @@ def main():
         regex.match_corpus_bits(corpus, out=out)
         b.record()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed_local = time.perf_counter() - t0
+    elapsed = elapsed_local
     kernel_ms = [a.elapsed_time(b) for a, b in ev]
+    per_rank = [round(nbytes * args.steps / elapsed_local / 1e9, 2)]
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        on = "cpu" if rehearsal == "1" else "cuda"
+        t = torch.tensor([elapsed_local], dtype=torch.float64, device=on)
+        every = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        per_rank = [round(nbytes * args.steps / float(x.item()) / 1e9, 2) for x in every]
 
     accepted = int(regex.match_corpus(corpus).sum(dtype=torch.int64).item())
     if rank == 0:
         avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
         achieved = nbytes / avg_kernel_s / 1e9
+        cold_GBs = nbytes / ((cold_index_ms + cold_match_ms) / 1e3) / 1e9
         res = {
             "metric": "GB/s input scanned (whole job), 256-state regex" if args.workload == "url" else "GB/s input scanned (whole job)",
             "value": round(world * nbytes * args.steps / elapsed / 1e9, 2),
             "unit": "GB/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4),
@@ -223,10 +302,15 @@ def main():
                        "pattern_states": regex.states_n, "useful_states": regex.useful_states, "engine": regex.engine_name,
                        "bytes_per_gpu": nbytes, "stripe_bytes": corpus.stripe, "lines_per_gpu": nlines, "accepted_rank0": accepted, "sharding": "by lines, no collective"},
             "per_gpu_GBs": round(nbytes * args.steps / elapsed / 1e9, 2),
+            "per_rank_GBs": per_rank,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": measured_traffic(args.workload, nbytes, regex.engine_name),
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "traffic_from_profile": traffic_from_profile(args.workload, nbytes, regex.engine_name),
                          "frac_of_read_stream_6.4TBs": round(achieved / HBM_ACHIEVABLE_GBS, 4),
                          "kernel_ms_avg": round(avg_kernel_s * 1e3, 4), "algorithmic_bytes_per_launch": nbytes},
+            # the same corpus met for the first time: newline index + one match (nothing reused); never the headline
+            "cold": {"index_ms": round(cold_index_ms, 4), "match_ms": round(cold_match_ms, 4), "GBs": round(cold_GBs, 2),
+                     "frac": round(cold_GBs / HBM_PEAK_GBS, 4)},
             "setup": {"generate_s": round(gen_s, 2), "index_ms": round(index_ms, 3)},
         }
         if args.pcie:

@@ -56,9 +56,7 @@ struct LineDfaEngine {
         // In the SDWA form the low half of an entry is the ABSOLUTE LDS address of the next row, so that
         // e.word[0] + 4*c is the address to read, with no base to add per byte.
         const uint32_t base = (WIDE && !CLAMP) ? (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds : 0u;
-#ifndef RRX_PROBE_NO_TABLE      /* measurement only */
         for (int i = threadIdx.x; i < n; i += blockDim.x) t[i] = p.table[i] + base;
-#endif
         if (!WIDE) {
             uint8_t *c = lds + (size_t)n * 4;
             for (int i = threadIdx.x; i < 256; i += blockDim.x) c[i] = p.cls[i];
@@ -84,10 +82,6 @@ struct LineDfaEngine {
     template <int K>
     __device__ __forceinline__ void consume(State &st, uint32_t w, uint32_t &bits) const {
         if constexpr (WIDE && !CLAMP) {
-#ifdef RRX_PROBE_NO_LOOKUP      /* measurement only: no table read (results are wrong) */
-            st.e = (st.e + (((w >> (8 * K)) & 0xffu) << col_shift)) & 0x1ffffu;
-            bits = (bits << ((st.e >> 16) & 1u)) | (st.e >> 24);
-#else
             // One asm block per byte (separate statements made hipcc pad every byte with an s_nop).  The block
             // waits for its own LDS read; the only other memory traffic of the wave are global loads (vmcnt).
             uint32_t t0, t1;
@@ -106,7 +100,6 @@ struct LineDfaEngine {
             if constexpr (K == 2) RRX_STEP("BYTE_2");
             if constexpr (K == 3) RRX_STEP("BYTE_3");
 #undef RRX_STEP
-#endif
         } else {
             uint32_t nl, acc;
             step(st, (w >> (8 * K)) & 0xffu, nl, acc);
@@ -117,16 +110,10 @@ struct LineDfaEngine {
         uint32_t col;
         if (WIDE) col = CLAMP ? (c < 128u ? c : 128u) : c;      // !CLAMP: the corpus holds no byte >= 0x80
         else col = cls[c];
-#ifdef RRX_PROBE_NO_LOOKUP      /* measurement only: same feed and result path, no table read (results are wrong) */
-        st.e = st.e * 33u + col;
-        nl = col == 10u ? 1u : 0u;
-        acc = st.e & nl;
-#else
         const uint32_t off = (st.e & 0xffffu) + (col << col_shift);      // (absolute LDS address in the SDWA form)
         st.e = (WIDE && !CLAMP) ? *reinterpret_cast<lds_u32_ptr>(off) : *reinterpret_cast<const uint32_t *>(tab + off);
         nl = (st.e >> 16) & 0xffu;
         acc = st.e >> 24;
-#endif
     }
 };
 
@@ -303,21 +290,9 @@ constexpr uint32_t kEndsOnNewline = 0x80000000u;         // bit 31 of counts[k]:
 constexpr uint64_t kFreshStripe = 1ull << 63;             // bit 63 of stripe_base[k]: stripe k begins at the start of a line
 __device__ __forceinline__ uint64_t line_of(uint64_t base) { return base & ~kFreshStripe; }
 
-// Text loads.  RRX_TEXT_NT=1 (measurement only) makes them non-temporal: the idea was to keep the streamed text from
-// displacing the accept bitmap's lines in L2, the effect is that the 8 loads of a 128-byte line no longer merge into
-// one request (-47 %).  The result window in LDS solved the bitmap problem instead.
-#ifndef RRX_TEXT_NT
-#define RRX_TEXT_NT 0
-#endif
-__device__ __forceinline__ uint4 load_text(const uint4 *p) {
-#if RRX_TEXT_NT
-    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(p));
-    return make_uint4(v.x, v.y, v.z, v.w);
-#else
-    return *p;
-#endif
-}
+// Text loads are plain loads: non-temporal ones stop the 8 loads of a 128-byte line from merging into one request
+// (measured -47 %, profiles/r01_v7_result_path_probes.txt).
+__device__ __forceinline__ uint4 load_text(const uint4 *p) { return *p; }
 
 // ============================================================================================ batch kernel
 // Line verdicts of one lane.  `bits` = sentinel 1 followed by one verdict bit per line finished since the
@@ -354,22 +329,10 @@ struct ResultsT {
     __device__ __forceinline__ void emit() {
         if (!outw || !writer) return;
         if (STAGED && word < stage_words) atomicOr(&stage[(uint32_t)word], outw);
-        else
-#if defined(RRX_PROBE_FLUSH_STORE)      /* measurement only: plain store instead of the atomic (wrong at shared words) */
-            out[word] = outw;
-#elif defined(RRX_PROBE_FLUSH_LOCAL)    /* measurement only: the atomics all land in 16 KiB that stay in L2 */
-            atomicOr(&out[word & 4095], outw);
-#elif defined(RRX_PROBE_FLUSH_NOMEM)    /* measurement only: the flush arithmetic without the memory operation */
-            asm volatile("" :: "v"(outw), "v"(word));
-#else
-            atomicOr(&out[word], outw);
-#endif
+        else atomicOr(&out[word], outw);
     }
     __device__ __forceinline__ void push(uint32_t nl, uint32_t acc) { bits = (bits << nl) | acc; }
     __device__ __forceinline__ void flush() {
-#ifdef RRX_PROBE_NO_FLUSH       /* measurement only */
-        seen += bits & 1u; bits = 1; return;
-#endif
         const int n = 31 - __clz((int)bits);
         if (n > 0) {                                         // n <= 31: callers flush before bits can overflow
             uint32_t rev = __brev(bits & ((1u << n) - 1u)) >> (32 - n);      // oldest line at bit 0
@@ -546,19 +509,8 @@ struct Dfa2 {
         asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(ia) : "v"(ta), "v"(w2));
         asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(tb) : "v"(w2), "v"(stride));
         asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(ib) : "v"(tb), "v"(w2));
-#if defined(RRX_PROBE_NO_LOOKUP)    /* measurement only: same feed, VALU work and result path, no LDS gathers (results are wrong) */
-#define RRX_LDS_U16(x) ((x) & 0x3cu)
-#define RRX_LDS_U32(x) ((x) & 0x0001ffffu)
-#elif defined(RRX_PROBE_NO_P)       /* measurement only: no pair-table gather (results are wrong) */
-#define RRX_LDS_U16(x) ((x) & 0x3cu)
-#define RRX_LDS_U32(x) (*reinterpret_cast<lds_u32_ptr>(x))
-#elif defined(RRX_PROBE_NO_T2)      /* measurement only: no state-table gather (results are wrong) */
-#define RRX_LDS_U16(x) (*reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(P) + (x)))
-#define RRX_LDS_U32(x) ((x) & 0x0001ffffu)
-#else
 #define RRX_LDS_U16(x) (*reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(P) + (x)))
 #define RRX_LDS_U32(x) (*reinterpret_cast<lds_u32_ptr>(x))
-#endif
         const uint32_t ca = RRX_LDS_U16(ia);
         const uint32_t cb = RRX_LDS_U16(ib);
         uint32_t addr;
