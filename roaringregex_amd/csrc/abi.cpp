@@ -65,8 +65,27 @@ struct rrx_regex {
     mutable int search_state = 0;        // 0 = not built, 1 = built, -1 = does not fit
     mutable DfaProgram search_fwd, search_rev;
     mutable std::map<int, SearchTablesOnDevice> search_on_device;
+    // Scratch of the single-string entries (rrx_match_string / rrx_match_cstr): one grow-only device buffer per device,
+    // kept across calls (a hipMalloc + hipFree pair per string cost more than the match itself).  `scratch_mu` is held
+    // for the whole call: those entries are synchronous, concurrent callers of one regex take turns.
+    struct Scratch { void *p = nullptr; size_t cap = 0; };
+    mutable std::mutex scratch_mu;
+    mutable std::map<int, Scratch> scratch;
+    int scratch_for(int device, size_t bytes, void **out) const {      // call with `scratch_mu` held
+        Scratch &sc = scratch[device];
+        if (sc.cap < bytes) {
+            if (sc.p) { (void)hipFree(sc.p); sc.p = nullptr; sc.cap = 0; }
+            const size_t want = bytes < 4096 ? 4096 : bytes + bytes / 4;
+            hipError_t e = hipMalloc(&sc.p, want);
+            if (e != hipSuccess) { sc.p = nullptr; return hip_fail(e, "hipMalloc(single-string scratch)"); }
+            sc.cap = want;
+        }
+        *out = sc.p;
+        return RRX_OK;
+    }
 
     ~rrx_regex() {
+        for (auto &kv : scratch) if (kv.second.p) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.p); }
         for (auto &kv : on_device) if (kv.second.blob) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.blob); }
         for (auto &kv : search_on_device) if (kv.second.blob) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.blob); }
     }
@@ -536,37 +555,47 @@ int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, cons
 
 // One device-resident string of any length.  Long strings take the chunk-map path when the automaton has a small
 // table (every chunk stepped from every state, maps composed); the rest is one item of the extents kernel.
+// `scratch`/`scratch_bytes`: caller-provided device memory (rrx_match_cstr passes the tail of its own buffer).
+static int match_string_with(const rrx_regex *re, int device, const DeviceTables *t, const uint8_t *d_bytes, size_t nbytes, uint8_t *d_accept,
+                             uint8_t *scratch, hipStream_t st) {
+    const bool table_engine = re->engine != RRX_ENGINE_NFA && re->engine != RRX_ENGINE_NFA_WAVE;
+    if (table_engine && nbytes >= kLongStringBytes && t->dfa.nstates && t->dfa.nstates <= dev::kLongMaxStates) {
+        uint32_t chunk = 0;
+        (void)dev::long_scratch_bytes(t->dfa.nstates, nbytes, &chunk);
+        int le = dev::match_long_dfa(t->dfa, d_bytes, nbytes, chunk, scratch, d_accept, st);
+        if (le) return hip_fail((hipError_t)le, "match_long launch");
+        return RRX_OK;
+    }
+    const uint64_t off[2] = {0, nbytes};
+    uint64_t *d_off = reinterpret_cast<uint64_t *>(scratch);
+    hipError_t e = hipMemcpyAsync(d_off, off, sizeof off, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);                    // `off` leaves scope
+    if (e != hipSuccess) return hip_fail(e, "extent upload");
+    return rrx_match_extents(re, device, d_bytes, d_off, 1, 0, d_accept, st);
+}
+static size_t match_string_scratch_bytes(const rrx_regex *re, const DeviceTables *t, size_t nbytes) {
+    const bool table_engine = re->engine != RRX_ENGINE_NFA && re->engine != RRX_ENGINE_NFA_WAVE;
+    if (table_engine && nbytes >= kLongStringBytes && t->dfa.nstates && t->dfa.nstates <= dev::kLongMaxStates) {
+        uint32_t chunk = 0;
+        return dev::long_scratch_bytes(t->dfa.nstates, nbytes, &chunk);
+    }
+    return 2 * sizeof(uint64_t);
+}
+
 int rrx_match_string(const rrx_regex *re, int device, const void *d_bytes, size_t nbytes, uint8_t *d_accept, void *stream) {
     if (!re || (nbytes && !d_bytes) || !d_accept) return fail(RRX_ERR_ARG, "null argument");
     const DeviceTables *t;
     int rc = re->tables(device, &t);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(device));
-    const bool table_engine = re->engine != RRX_ENGINE_NFA && re->engine != RRX_ENGINE_NFA_WAVE;
-    if (table_engine && nbytes >= kLongStringBytes && t->dfa.nstates && t->dfa.nstates <= dev::kLongMaxStates) {
-        uint32_t chunk = 0;
-        const size_t need = dev::long_scratch_bytes(t->dfa.nstates, nbytes, &chunk);
-        void *scratch = nullptr;
-        hipError_t e = hipMalloc(&scratch, need);
-        if (e != hipSuccess) return hip_fail(e, "hipMalloc(chunk maps)");
-        int le = dev::match_long_dfa(t->dfa, static_cast<const uint8_t *>(d_bytes), nbytes, chunk, scratch, d_accept, stream);
-        e = hipStreamSynchronize(static_cast<hipStream_t>(stream));           // the maps are freed next
-        (void)hipFree(scratch);
-        if (le) return hip_fail((hipError_t)le, "match_long launch");
-        if (e != hipSuccess) return hip_fail(e, "match_long");
-        return RRX_OK;
-    }
-    uint64_t *d_off = nullptr;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d_off), 2 * sizeof(uint64_t));
-    if (e != hipSuccess) return hip_fail(e, "hipMalloc(extent)");
-    const uint64_t off[2] = {0, nbytes};
-    e = hipMemcpyAsync(d_off, off, sizeof off, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream));
-    if (e == hipSuccess) e = hipStreamSynchronize(static_cast<hipStream_t>(stream));     // `off` leaves scope
-    if (e != hipSuccess) rc = hip_fail(e, "extent upload");
-    if (!rc) rc = rrx_match_extents(re, device, d_bytes, d_off, 1, 0, d_accept, stream);
-    e = hipStreamSynchronize(static_cast<hipStream_t>(stream));
+    std::lock_guard<std::mutex> lock(re->scratch_mu);
+    void *scratch = nullptr;
+    rc = re->scratch_for(device, match_string_scratch_bytes(re, t, nbytes), &scratch);
+    if (rc) return rc;
+    rc = match_string_with(re, device, t, static_cast<const uint8_t *>(d_bytes), nbytes, d_accept, static_cast<uint8_t *>(scratch),
+                           static_cast<hipStream_t>(stream));
+    const hipError_t e = hipStreamSynchronize(static_cast<hipStream_t>(stream));      // the scratch is reused by the next call
     if (!rc && e != hipSuccess) rc = hip_fail(e, "match_string");
-    (void)hipFree(d_off);
     return rc;
 }
 
@@ -663,18 +692,22 @@ int rrx_match_cstr(const rrx_regex *re, int device, const char *text, int *accep
     if (!re || !text || !accepted) return fail(RRX_ERR_ARG, "null argument");
     const size_t n = std::strlen(text);                       // regex.h:157: consume up to the terminator
     if (len) *len = n;
+    const DeviceTables *t;
+    int rc = re->tables(device, &t);
+    if (rc) return rc;
     HIP_TRY(hipSetDevice(device));
-    uint8_t *d = nullptr;
-    const size_t acc_at = (n + 15) & ~(size_t)15;
-    hipError_t e = hipMalloc(reinterpret_cast<void **>(&d), acc_at + 16);
-    if (e != hipSuccess) return hip_fail(e, "hipMalloc(text)");
-    int rc = RRX_OK;
-    if (n) e = hipMemcpy(d, text, n, hipMemcpyHostToDevice);
-    if (e != hipSuccess) rc = hip_fail(e, "text upload");
-    if (!rc) rc = rrx_match_string(re, device, d, n, d + acc_at, nullptr);
+    // one persistent device buffer: [text, padded to 16 | accept byte, padded to 16 | scratch of the match]
+    std::lock_guard<std::mutex> lock(re->scratch_mu);
+    const size_t acc_at = (n + 15) & ~(size_t)15, scratch_at = acc_at + 16;
+    void *buf = nullptr;
+    rc = re->scratch_for(device, scratch_at + match_string_scratch_bytes(re, t, n), &buf);
+    if (rc) return rc;
+    uint8_t *d = static_cast<uint8_t *>(buf);
+    hipError_t e = n ? hipMemcpy(d, text, n, hipMemcpyHostToDevice) : hipSuccess;
+    if (e != hipSuccess) return hip_fail(e, "text upload");
+    rc = match_string_with(re, device, t, d, n, d + acc_at, d + scratch_at, nullptr);
     uint8_t a = 0;
     if (!rc) { e = hipMemcpy(&a, d + acc_at, 1, hipMemcpyDeviceToHost); if (e != hipSuccess) rc = hip_fail(e, "accept readback"); }
-    (void)hipFree(d);
     *accepted = a;
     return rc;
 }

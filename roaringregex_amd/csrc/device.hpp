@@ -60,6 +60,8 @@ struct DfaDevice {
     const uint8_t *acc = nullptr;                // [nstates]
 };
 
+constexpr size_t kPlainDfaLdsBudget = 64 * 1024;   // larger plain tables are read from HBM/L2 by the extents kernel
+
 // Line-mode DFA tables (batch kernel): the '\n' transition of every row goes to the start row and carries
 // the verdict of the line that just ended.  Entry = next row byte offset (16 bits) | nl << 16 | accept << 24.
 struct LineDfaDevice {

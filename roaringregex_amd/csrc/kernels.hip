@@ -21,6 +21,8 @@
 //     the corpus carries (8 bytes per stripe of text): no per-line offset array is ever read.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include "device.hpp"
 
 
@@ -284,6 +286,26 @@ struct PlainDfaEngine {
     __device__ __forceinline__ void kill(State &st) const { st.s = 0; }
     __device__ __forceinline__ bool accepting(const State &st) const { return acc[st.s] != 0; }
     __device__ __forceinline__ void step(State &st, uint32_t c) const { st.s = next[st.s * ncls + cls[c]]; }
+};
+
+// The same automaton with its table left in HBM/L2 (tables beyond the LDS budget: the batch kernel's "global" form,
+// here for explicit items and single strings).  One dependent L2 read per byte.
+struct PlainDfaGlobalEngine {
+    struct State { uint32_t s; };
+    const uint8_t *cls;                   // LDS [256]
+    const uint16_t *__restrict__ next;    // HBM / L2 [nstates][ncls]
+    const uint8_t *__restrict__ acc;      // HBM / L2 [nstates]
+    uint32_t ncls, start;
+
+    static size_t lds_bytes(const DfaDevice &) { return 256; }
+    __device__ void load(const DfaDevice &p, uint8_t *lds) {
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) lds[i] = p.cls[i];
+        cls = lds; next = p.next; acc = p.acc; ncls = p.ncls; start = p.start;
+    }
+    __device__ __forceinline__ void reset(State &st) const { st.s = start; }
+    __device__ __forceinline__ void kill(State &st) const { st.s = 0; }
+    __device__ __forceinline__ bool accepting(const State &st) const { return acc[st.s] != 0; }
+    __device__ __forceinline__ void step(State &st, uint32_t c) const { st.s = next[(size_t)st.s * ncls + cls[c]]; }
 };
 
 constexpr uint32_t kEndsOnNewline = 0x80000000u;         // bit 31 of counts[k]: stripe k ends on a '\n'
@@ -926,6 +948,21 @@ __global__ __launch_bounds__(256) void scan_chunks_kernel(const uint32_t *__rest
     }
 }
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel, device and size increase, not once per launch.
+// (One slot array per kernel: `slots` is a function-local static of the calling template instantiation.)
+constexpr int kMaxDevices = 64;
+struct LdsAttr { std::atomic<int> bytes[kMaxDevices]; };
+inline hipError_t ensure_dynamic_lds(LdsAttr &slots, const void *kernel, size_t bytes) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= kMaxDevices) return hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (slots.bytes[dev].load(std::memory_order_acquire) >= (int)bytes) return hipSuccess;
+    e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) slots.bytes[dev].store((int)bytes, std::memory_order_release);
+    return e;
+}
+
 template <class Engine, class Program>
 int launch_stripes(const Program &p, size_t table_bytes, const uint8_t *bytes, size_t nbytes, uint32_t stripe,
                    const uint64_t *stripe_base, size_t nstripes, uint32_t *accept, void *stream) {
@@ -936,7 +973,8 @@ int launch_stripes(const Program &p, size_t table_bytes, const uint8_t *bytes, s
     const size_t half_cu = 80 * 1024;
     const uint32_t stage_words = stage_off + kStageWords * sizeof(uint32_t) >= half_cu ? kStageWords : (uint32_t)((half_cu - stage_off) / 4);
     const size_t lds = Engine::kStaged ? stage_off + (size_t)stage_words * sizeof(uint32_t) : table_bytes;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static LdsAttr attr;
+    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(k), lds);
     if (e != hipSuccess) return (int)e;
     size_t blocks = (nstripes + kThreads - 1) / kThreads;
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept, stage_off, stage_words);
@@ -1123,7 +1161,8 @@ int launch_extents(const Program &p, size_t table_bytes, const uint8_t *bytes, c
                    uint8_t *accept, void *stream) {
     if (!nitems) return 0;
     auto k = match_extents_kernel<Engine, Program>;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)table_bytes);
+    static LdsAttr attr;
+    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(k), table_bytes);
     if (e != hipSuccess) return (int)e;
     size_t blocks = (nitems + kThreads - 1) / kThreads;
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), table_bytes, (hipStream_t)stream, p, bytes, off, nitems, trim, accept);
@@ -1224,7 +1263,8 @@ int search_lines(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, con
     if (!nlines) return 0;
     const size_t lds = search_lds_bytes(p);
     if (lds > kSearchLdsBudget || p.nf > 32767 || p.nr > 32767) return (int)hipErrorInvalidValue;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(search_lines_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static LdsAttr attr;
+    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(search_lines_kernel), lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(search_lines_kernel, dim3((unsigned)((nlines + 255) / 256)), dim3(256), lds, (hipStream_t)stream, p, bytes, nbytes, line_off, nlines,
                        match_start, match_end);
@@ -1236,8 +1276,9 @@ int search_all(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, const
     const size_t lds = search_lds_bytes(p);
     if (lds > kSearchLdsBudget || p.nf > 32767 || p.nr > 32767) return (int)hipErrorInvalidValue;
     const bool fill = first != nullptr;
-    hipError_t e = fill ? hipFuncSetAttribute(reinterpret_cast<const void *>(search_all_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)
-                        : hipFuncSetAttribute(reinterpret_cast<const void *>(search_all_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static LdsAttr attr_fill, attr_count;
+    hipError_t e = fill ? ensure_dynamic_lds(attr_fill, reinterpret_cast<const void *>(search_all_kernel<true>), lds)
+                        : ensure_dynamic_lds(attr_count, reinterpret_cast<const void *>(search_all_kernel<false>), lds);
     if (e != hipSuccess) return (int)e;
     const dim3 grid((unsigned)((nlines + 255) / 256));
     if (fill) hipLaunchKernelGGL(search_all_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, p, bytes, nbytes, line_off, nlines, count, first, match_start, match_end);
@@ -1259,7 +1300,8 @@ int match_long_dfa(const DfaDevice &p, const uint8_t *bytes, size_t nbytes, uint
     const uint32_t D = p.nstates;
     if (!D || D > kLongMaxStates || !nbytes) return (int)hipErrorInvalidValue;
     const size_t lds = (size_t)D * kWideColumns * sizeof(uint16_t);
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(long_maps_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    static LdsAttr attr;
+    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(long_maps_kernel), lds);
     if (e != hipSuccess) return (int)e;
     uint32_t n = (uint32_t)((nbytes + chunk - 1) / chunk);
     uint16_t *cur = static_cast<uint16_t *>(scratch), *other = cur + (size_t)n * D;
@@ -1279,6 +1321,9 @@ int match_long_dfa(const DfaDevice &p, const uint8_t *bytes, size_t nbytes, uint
 }
 int match_extents_dfa(const DfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim, uint8_t *accept,
                       void *stream) {
+    // tables beyond the LDS budget (the batch kernel's "global" form) stay in HBM/L2 here too
+    if (PlainDfaEngine::lds_bytes(p) > kPlainDfaLdsBudget)
+        return launch_extents<PlainDfaGlobalEngine, DfaDevice>(p, PlainDfaGlobalEngine::lds_bytes(p), bytes, off, nitems, trim, accept, stream);
     return launch_extents<PlainDfaEngine, DfaDevice>(p, PlainDfaEngine::lds_bytes(p), bytes, off, nitems, trim, accept, stream);
 }
 

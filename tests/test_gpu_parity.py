@@ -297,6 +297,123 @@ def test_full_size_url_config_properties():
         assert (got == want).all(), j
 
 
+def _newlines_before(dev, off, piece=1 << 28):
+    """number of '\n' in dev[:off], counted on the device piece by piece"""
+    total = 0
+    for a in range(0, off, piece):
+        total += int((dev[a:min(a + piece, off)] == 10).sum(dtype=torch.int64).item())
+    return total
+
+
+def _full_size_properties(kind, seed, pattern, n, engines, chunks, accept_band):
+    """Shared body of the full-size tests of the >256-state configs: every engine gives the SAME bitmap; sampled 1 MiB
+    chunks (each ends with a newline by construction) reproduce the ORACLE's vector at their line offsets."""
+    import synth
+    host = synth.corpus(kind, seed, n)
+    dev = torch.empty(n, dtype=torch.uint8, device="cuda")
+    step = 1 << 30
+    for off in range(0, n, step):
+        dev[off:off + step].copy_(torch.from_numpy(host[off:off + step]))
+    corpus = rr.Corpus(dev)
+    ref_bits = None
+    for e in engines:
+        r = rr.RRegex(pattern, e)
+        bits = r.match_corpus_bits(corpus).clone()
+        if ref_bits is None:
+            ref_bits, ref_name = bits, r.engine_name
+        else:
+            assert torch.equal(bits, ref_bits), (kind, r.engine_name, "vs", ref_name)
+        del bits
+    nlines = corpus.num_lines
+    acc = rr.RRegex(pattern).match_corpus(corpus)                     # byte-per-line form of the same result
+    ones = int(acc.sum(dtype=torch.int64).item())
+    del acc
+    assert accept_band[0] < ones / nlines < accept_band[1], (kind, ones, nlines)
+    chunk = 1 << 20
+    o = OracleRegex(pattern)
+    for j in chunks:
+        piece = host[j * chunk:(j + 1) * chunk]
+        first = _newlines_before(dev, j * chunk)
+        want = o.match_lines(piece)
+        w0, w1 = first >> 5, (first + len(want) + 31) >> 5
+        words = ref_bits[w0:w1].cpu().numpy().view(np.uint32)
+        got = ((words[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).astype(np.uint8).reshape(-1)[first - 32 * w0:][:len(want)]
+        assert (got == want).all(), (kind, "chunk", j)
+
+
+def test_full_size_arepeat_config_properties():
+    """BASELINE config 4 (a{1,300}, 899 reference states: the Roaring class) at its per-GPU size of 1 GiB."""
+    _full_size_properties("arepeat", 3, "a{1,300}", 1 << 30, (rr.ENGINE_DFA2, rr.ENGINE_DFA, rr.ENGINE_NFA), (0, 1, 513, 1023), (0.6, 0.9))
+
+
+def test_full_size_kwlines_config_properties():
+    """BASELINE config 5(i) (k1|...|k1000, 7786 reference states) at its per-GPU size of 8 GiB: 1.58 G lines of 5.4
+    bytes, i.e. nearly every result word leaves the workgroup's LDS window (the direct-to-memory overflow path)."""
+    _full_size_properties("kwlines", 4, K1000, 8 << 30, (rr.ENGINE_DFA2, rr.ENGINE_DFA, rr.ENGINE_NFA), (0, 2, 4097, 8191), (0.4, 0.6))
+
+
+def test_full_size_kwlog_config_properties():
+    """BASELINE config 5(ii) (.*(k1|...|k1000).* over log lines) at 8 GiB per GPU."""
+    _full_size_properties("kwlog", 4, K1000_CONTAINS, 8 << 30, (rr.ENGINE_DFA2, rr.ENGINE_DFA, rr.ENGINE_NFA), (0, 3, 4098, 8191), (0.2, 0.8))
+
+
+def test_nul_bytes_in_a_seven_bit_corpus_reach_the_stride2_kernel():
+    """A corpus with 0x00 bytes but no byte >= 0x80 keeps the stride-2 engine (has_high stays false): its pair table row
+    and column 0 must send the line to the dead state.  All table engines and the NFA, every stripe size."""
+    rng = np.random.default_rng(33)
+    alphabet = np.frombuffer(b"ab\n\x00", dtype=np.uint8)
+    for n in (5, 4096 + 3, 300_001):
+        data = alphabet[rng.choice(4, size=n, p=[0.45, 0.45, 0.07, 0.03])].copy()
+        assert data.max() < 0x80
+        assert rr.RRegex("(a|b)*abb(a|b)*", rr.ENGINE_DFA2).engine_name == "dfa-stride2-table"
+        want = check("(a|b)*abb(a|b)*", data, stripes=STRIPES)
+        check("(a|b)*", data, stripes=STRIPES)
+    lines = [b"ab", b"a\x00b", b"\x00", b"", b"ab\x00", b"\x00ab", b"ab"]
+    want = check("(a|b)*", b"\n".join(lines) + b"\n")
+    assert list(want) == [1, 0, 0, 1, 0, 0, 1]
+
+
+def test_short_lines_overflow_the_workgroup_result_window():
+    """More lines inside one workgroup than its LDS result window holds (131 k - 620 k): several MiB of 1-2 byte lines at
+    stripe 1024 send most result words down the direct global-atomic path.  Table engines and the NFA vs the oracle."""
+    rng = np.random.default_rng(34)
+    data = np.frombuffer(b"a\n\n", dtype=np.uint8)[rng.integers(0, 3, size=6 << 20)].copy()
+    check("a?", data, stripes=(1024, 4096))
+    data = np.frombuffer(b"ab\n", dtype=np.uint8)[rng.integers(0, 3, size=(3 << 20) + 77)].copy()
+    check("(a|b)b?", data, stripes=(1024,))
+
+
+def test_large_global_table_automaton_through_every_entry_point():
+    """A 3000-word alternation: ~9.9 k interned sets, far beyond LDS -> dfa-global-table.  The batch kernel, the extents
+    kernel and the reference's own API (get_acceptance_iter(text)++; *it, regex.h:225-227) must all work on it: the
+    single-string entries read the plain table from HBM/L2 when it does not fit LDS."""
+    rng = random.Random(5)
+    words = sorted({"".join(rng.choice("abcdefghijklmnopqrstuvwxyz") for _ in range(rng.randint(4, 9))) for _ in range(3000)})
+    pattern = "|".join(words)
+    r = rr.RRegex(pattern)
+    assert r.engine_name == "dfa-global-table"
+    o = OracleRegex(pattern)
+    items = []
+    for w in rng.sample(words, 150):
+        items += [w, w + "x", w[:-1], w[1:], w + w]
+    items += ["", "zzzz"]
+    want = [int(o.accepts(t)) for t in items]
+    assert 100 < sum(want) < len(want)
+    blob = "".join(items).encode()
+    off = np.cumsum([0] + [len(t) for t in items]).astype(np.int64)
+    got = r.match_extents(torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).cuda(), torch.from_numpy(off).cuda()).cpu().numpy()
+    assert list(got) == want
+    got = r.match_corpus(rr.Corpus(("\n".join(items)).encode())).cpu().numpy()
+    assert list(got) == want
+    for t, w in list(zip(items, want))[:40]:
+        m = r.get_acceptance_iter(t).advance().value()
+        assert (m is not None) == bool(w), t
+        if m is not None:
+            assert (m.start, m.end) == (0, len(t))
+    dev = torch.from_numpy(np.frombuffer(words[7].encode(), dtype=np.uint8).copy()).cuda()
+    assert r.match_string(dev) is True
+
+
 def test_wave_cooperative_engine_on_large_automata():
     """Automata beyond 512 positions whose subset construction explodes (AUTO -> nfa-wave-cooperative), against the
     oracle: batch kernel at several stripe sizes, and the single-string entry."""

@@ -34,6 +34,7 @@ while done < npat:
     mix = rng.choice(["short", "empty-heavy", "long", "mixed"])
     lines = []
     total = 0
+    seven_bit = done % 2 == 0
     target = big if big else rng.choice([3000, 40000, 300000])
     while total < target:
         if mix == "short": n = rng.choice([0, 1, 2, 3, 5, 8])
@@ -43,7 +44,10 @@ while done < npat:
         s = random_text(rng, "abcxk01.d", n) if n <= 30 else "".join(rng.choice("abcxk01.d") for _ in range(n))
         b = s.encode()
         r = rng.random()
-        if r < 0.02 and b: b = b[: len(b) // 2] + bytes([rng.choice([0x80, 0xc3, 0xff, 0x01, 0x7f])]) + b[len(b) // 2:]
+        # every other corpus stays 7-bit (0x00, 0x01, 0x7f only), so that NUL bytes also reach the stride-2 kernel:
+        # a byte >= 0x80 anywhere routes the whole corpus to the byte-stride kernel
+        bad_bytes = [0x00, 0x01, 0x7f] if seven_bit else [0x80, 0xc3, 0xff, 0x00, 0x01, 0x7f]
+        if r < 0.02 and b: b = b[: len(b) // 2] + bytes([rng.choice(bad_bytes)]) + b[len(b) // 2:]
         lines.append(b)
         total += len(b) + 1
     data = b"\n".join(lines) + (b"\n" if rng.random() < 0.7 else b"")
