@@ -37,6 +37,8 @@ WORKLOADS = {
     "arepeat": ("arepeat", "A300", 1 << 30, "configs[3]: a{1,300} (4 GiB over 4 GPUs = 1 GiB per GPU)"),
     "kwlines": ("kwlines", "K1000", 8 << 30, "configs[4](i): k1|...|k1000 over lines k<n> (64 GiB over 8 GPUs = 8 GiB per GPU)"),
     "kwlog": ("kwlog", "K1000C", 8 << 30, "configs[4](ii): .*(k1|...|k1000).* over log lines (8 GiB per GPU)"),
+    # not a BASELINE config: the pattern class only an NFA engine can run (its subset construction has 2^41 sets)
+    "nondet": ("ablines", "NONDET", 8 << 30, "extra: (a|b)*a(a|b){40} over lines of a/b (no DFA exists within memory)"),
 }
 
 
@@ -49,7 +51,8 @@ def patterns():
         kat = json.load(f)
     u2 = [k["pattern"] for k in kat["kat"] if k["pattern"].startswith("(http|https|ftp)")][0]
     k1000 = kat["big_states"][-1]["pattern"]
-    return {"U2": u2, "EMAIL": r"[A-Za-z0-9._]+@[A-Za-z0-9.]+", "A300": "a{1,300}", "K1000": k1000, "K1000C": ".*(" + k1000 + ").*"}
+    return {"U2": u2, "EMAIL": r"[A-Za-z0-9._]+@[A-Za-z0-9.]+", "A300": "a{1,300}", "K1000": k1000, "K1000C": ".*(" + k1000 + ").*",
+            "NONDET": "(a|b)*a(a|b){40}"}
 
 
 def traffic_from_profile(workload, nbytes, engine_name):

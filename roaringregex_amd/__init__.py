@@ -94,6 +94,27 @@ def _check(rc):
         raise RRegexError(_L.rrx_last_error().decode("latin-1"))
 
 
+class _on:
+    """Run a method body on `device` and, when the caller names a stream, with that stream as torch's CURRENT stream:
+    the tensors the body allocates, torch ops such as cumsum/item and the native launches then all live on one stream
+    (the native calls are handed the same stream by _stream_ptr)."""
+
+    def __init__(self, device, stream):
+        import torch
+        self._dev = torch.cuda.device(device)
+        self._st = torch.cuda.stream(stream) if stream is not None else None
+
+    def __enter__(self):
+        self._dev.__enter__()
+        if self._st is not None:
+            self._st.__enter__()
+
+    def __exit__(self, *exc):
+        if self._st is not None:
+            self._st.__exit__(*exc)
+        return self._dev.__exit__(*exc)
+
+
 def _stream_ptr(stream):
     if stream is None:
         import torch
@@ -154,7 +175,7 @@ class Corpus:
         self.data = data                       # keeps the bytes alive
         self.device = data.device.index
         self._h = C.c_void_p()
-        with torch.cuda.device(self.device):
+        with _on(self.device, stream):
             _check(_L.rrx_corpus_create_ex(self.device, C.c_void_p(data.data_ptr() if data.numel() else 0), data.numel(),
                                            stripe, _stream_ptr(stream), C.byref(self._h)))
 
@@ -204,10 +225,10 @@ class RRegex:
         line i accepted.  Asynchronous on `stream`."""
         import torch
         nw = _L.rrx_corpus_bitmap_words(corpus._h)
-        if out is None:
-            out = torch.empty(nw, dtype=torch.int32, device=corpus.data.device)
-        assert out.is_cuda and out.dtype == torch.int32 and out.numel() >= nw
-        with torch.cuda.device(corpus.device):
+        with _on(corpus.device, stream):
+            if out is None:
+                out = torch.empty(nw, dtype=torch.int32, device=corpus.data.device)
+            assert out.is_cuda and out.dtype == torch.int32 and out.numel() >= nw
             _check(_L.rrx_match_corpus(self._h, corpus._h, C.c_void_p(out.data_ptr() if nw else 0), _stream_ptr(stream)))
         return out[:nw]
 
@@ -215,11 +236,11 @@ class RRegex:
         """accept[i] = 1 iff line i of the corpus is accepted (one byte per line: bitmap + expansion)."""
         import torch
         n = corpus.num_lines
-        bits = self.match_corpus_bits(corpus, stream=stream)
-        if out is None:
-            out = torch.empty(n, dtype=torch.uint8, device=corpus.data.device)
-        assert out.is_cuda and out.dtype == torch.uint8 and out.numel() >= n
-        with torch.cuda.device(corpus.device):
+        with _on(corpus.device, stream):
+            bits = self.match_corpus_bits(corpus, stream=stream)
+            if out is None:
+                out = torch.empty(n, dtype=torch.uint8, device=corpus.data.device)
+            assert out.is_cuda and out.dtype == torch.uint8 and out.numel() >= n
             _check(_L.rrx_bitmap_to_bytes(corpus.device, C.c_void_p(bits.data_ptr() if n else 0), n,
                                           C.c_void_p(out.data_ptr() if n else 0), _stream_ptr(stream)))
         return out[:n]
@@ -229,9 +250,9 @@ class RRegex:
         tensors of offsets relative to the start of the string; (-1, -1) where nothing is accepted."""
         import torch
         n = corpus.num_lines
-        start = torch.empty(n, dtype=torch.int32, device=corpus.data.device)
-        end = torch.empty(n, dtype=torch.int32, device=corpus.data.device)
-        with torch.cuda.device(corpus.device):
+        with _on(corpus.device, stream):
+            start = torch.empty(n, dtype=torch.int32, device=corpus.data.device)
+            end = torch.empty(n, dtype=torch.int32, device=corpus.data.device)
             _check(_L.rrx_search_corpus(self._h, corpus._h, C.c_void_p(start.data_ptr() if n else 0), C.c_void_p(end.data_ptr() if n else 0),
                                         _stream_ptr(stream)))
         return start, end
@@ -242,8 +263,8 @@ class RRegex:
         import torch
         n = corpus.num_lines
         dev = corpus.data.device
-        count = torch.zeros(n, dtype=torch.int32, device=dev)
-        with torch.cuda.device(corpus.device):
+        with _on(corpus.device, stream):
+            count = torch.zeros(n, dtype=torch.int32, device=dev)
             _check(_L.rrx_search_all_count(self._h, corpus._h, C.c_void_p(count.data_ptr() if n else 0), _stream_ptr(stream)))
             inclusive = torch.cumsum(count, dim=0, dtype=torch.int64)
             first = inclusive - count
@@ -260,9 +281,9 @@ class RRegex:
         import torch
         n = offsets.numel() - 1
         assert data.is_cuda and offsets.is_cuda and offsets.dtype in (torch.int64, torch.uint64)
-        if out is None:
-            out = torch.empty(n, dtype=torch.uint8, device=data.device)
-        with torch.cuda.device(data.device.index):
+        with _on(data.device.index, stream):
+            if out is None:
+                out = torch.empty(n, dtype=torch.uint8, device=data.device)
             _check(_L.rrx_match_extents(self._h, data.device.index, C.c_void_p(data.data_ptr() if data.numel() else 0),
                                         C.c_void_p(offsets.data_ptr()), n, trim, C.c_void_p(out.data_ptr() if n else 0),
                                         _stream_ptr(stream)))
@@ -272,8 +293,8 @@ class RRegex:
         """ONE device-resident string of any length (regex.h:156-159); '\n' is an ordinary character.  -> bool"""
         import torch
         assert data.is_cuda and data.dtype == torch.uint8
-        out = torch.zeros(1, dtype=torch.uint8, device=data.device)
-        with torch.cuda.device(data.device.index):
+        with _on(data.device.index, stream):
+            out = torch.zeros(1, dtype=torch.uint8, device=data.device)
             _check(_L.rrx_match_string(self._h, data.device.index, C.c_void_p(data.data_ptr() if data.numel() else 0), data.numel(),
                                        C.c_void_p(out.data_ptr()), _stream_ptr(stream)))
         return bool(out.item())

@@ -157,6 +157,7 @@ struct rrx_regex {
             oB = put(B.data(), B.size() * 4);
             oX = put(X.data(), X.size() * 4);
             t.nfa.W = WP; t.nfa.nbits = nfa.nbits; t.nfa.any_exc = nfa.n_exc ? 1 : 0; t.nfa.any_carry = nfa.n_carry ? 1 : 0;
+            for (uint32_t w = 0; w < W; w++) if (nfa.self[w]) t.nfa.any_self = 1;
             std::memset(&t.nfa.masks, 0, sizeof t.nfa.masks);
             for (uint32_t w = 0; w < W; w++) {
                 t.nfa.masks.init[w] = nfa.init[w]; t.nfa.masks.fin[w] = nfa.fin[w]; t.nfa.masks.chain[w] = nfa.chain[w];
@@ -290,7 +291,7 @@ int rrx_compile_ex(const char *pattern, int engine, rrx_regex **out) {
         re->ref = build_reference_automaton(re->pattern);
         re->trimmed = trim(re->ref);
         const Reduced red = reduce(re->trimmed);
-        if (engine == RRX_ENGINE_AUTO || engine == RRX_ENGINE_NFA) re->has_nfa = lower_nfa(red, dev::kMaxNfaWords * 32, re->nfa);
+        if (engine == RRX_ENGINE_AUTO || engine == RRX_ENGINE_NFA) re->has_nfa = lower_nfa(red, dev::kMaxNfaWords * 32, re->nfa, /*allow_carry=*/true, /*gaps=*/true);
         if (engine != RRX_ENGINE_NFA && engine != RRX_ENGINE_NFA_WAVE) {     // (DFA, DFA_GLOBAL, DFA2, AUTO)
             re->has_dfa = lower_dfa(red, kMaxSubsetStates, re->dfa);
             if (re->has_dfa) {

@@ -36,7 +36,7 @@ struct NfaMasks {                                // passed by value -> SGPRs
 };
 
 struct NfaDevice {                               // tables in HBM (copied to LDS by every workgroup)
-    uint32_t W = 0, nbits = 0, any_exc = 0, any_carry = 0;
+    uint32_t W = 0, nbits = 0, any_exc = 0, any_carry = 0, any_self = 0;
     NfaMasks masks;
     const uint32_t *B = nullptr;                 // [256][W]
     const uint32_t *X = nullptr;                 // [nbits][W]

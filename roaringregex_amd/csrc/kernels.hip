@@ -42,6 +42,7 @@ template <bool WIDE, bool CLAMP>
 struct LineDfaEngine {
     static constexpr bool kStaged = true;      // results go through the workgroup's LDS window (ResultsT<true>)
     static constexpr bool kEightWaves = false;
+    static constexpr int kRoundBytes = kRound;
     // Table entry: bits 0..15 = byte offset of the next row, byte 2 = 1 iff the consumed byte was '\n',
     // byte 3 = verdict of the line it ended.  (16-bit entries read with ds_read_u16 measured 3-4 % slower.)
     struct State { uint32_t e; };
@@ -108,6 +109,9 @@ struct LineDfaEngine {
             bits = (bits << nl) | acc;
         }
     }
+    __device__ __forceinline__ void consume_word(State &st, uint32_t w, uint32_t &bits) const {
+        consume<0>(st, w, bits); consume<1>(st, w, bits); consume<2>(st, w, bits); consume<3>(st, w, bits);
+    }
     __device__ __forceinline__ void step(State &st, uint32_t c, uint32_t &nl, uint32_t &acc) const {
         uint32_t col;
         if (WIDE) col = CLAMP ? (c < 128u ? c : 128u) : c;      // !CLAMP: the corpus holds no byte >= 0x80
@@ -123,6 +127,7 @@ struct LineDfaEngine {
 struct LineDfaGlobalEngine {
     static constexpr bool kStaged = true;
     static constexpr bool kEightWaves = false;
+    static constexpr int kRoundBytes = kRound;
     struct State { uint32_t e; };          // low 24 bits = index of the current row's first entry
     const uint32_t *__restrict__ tab;      // HBM / L2
     const uint8_t *cls;                    // LDS [256]
@@ -145,6 +150,9 @@ struct LineDfaGlobalEngine {
         uint32_t nl, acc;
         step(st, (w >> (8 * K)) & 0xffu, nl, acc);
         bits = (bits << nl) | acc;
+    }
+    __device__ __forceinline__ void consume_word(State &st, uint32_t w, uint32_t &bits) const {
+        consume<0>(st, w, bits); consume<1>(st, w, bits); consume<2>(st, w, bits); consume<3>(st, w, bits);
     }
 };
 
@@ -210,15 +218,40 @@ struct NfaCore {
     }
 };
 
-template <int W>
+// ---- line-mode shift-and NFA (the batch kernel's NFA engine): NFA.cc:86-100 restated for one string per lane with the
+// state set in W registers and the per-character bitmaps B[c] in LDS.  Everything the line protocol needs is folded
+// into the automaton, so that a byte costs no compare and no re-initialisation:
+//   * position 0 is the initial state.  The shift injects a 1 into it on EVERY byte, t0 = (S0 << 1) | 1, and only
+//     B['\n'] contains position 0: after a '\n' the set is exactly {initial}, after any other byte position 0 is
+//     clear.  Bytes 0x00 and >= 0x80 have empty rows: the set dies and stays dead until the next '\n'.
+//   * the lowering leaves a never-entered gap position in front of every path of the path cover (lower_nfa, gaps),
+//     so the bit shifted out of a path's end dies in the gap: no CHAIN mask.
+//   * the verdict (S & FIN != 0, NFA.cc:103-107) is only evaluated in byte steps where SOME lane of the wave sits on a
+//     '\n' (one SDWA compare + a scalar branch otherwise).
+// Per byte and word: 1 shift (v_alignbit / v_lshl_or) + 1 AND with the B word, + 1 v_and_or for the self loops when
+// the automaton has any (SELF) ; RULES adds the add-carry groups and the exception rows of NfaCore.
+template <int W, bool SELF, bool RULES>
 struct LineNfaEngine : NfaCore<W> {
-    static constexpr bool kStaged = false;     // measured 10 % slower with the window (register pressure)
-    static constexpr bool kEightWaves = true;
+    // Measured on the builds with rules (profiles/r02_nfa_variants.txt): the LDS result window and the four-rows-ahead
+    // fetch each cost them 4-20 % (registers; their time goes to the exception loop), the plain builds gain from both.
+    static constexpr bool kStaged = !RULES;
+    static constexpr bool kEightWaves = W <= 2 && !RULES;      // 64 registers = two workgroups per CU
+    static constexpr int kRoundBytes = W <= 4 ? kRound : kRound / 2;
     using State = typename NfaCore<W>::State;
+    __device__ void load(const NfaDevice &p, uint8_t *lds) {
+        NfaCore<W>::load(p, lds);
+        // The byte step uses byte * row bytes as the LDS address of a B row: B must sit at LDS address 0, which it does
+        // as long as the kernel has no static LDS in front of its dynamic LDS.  (Adding the base would be a sixth VALU
+        // instruction per byte: the base is a relocation, not an immediate.)
+        if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds != 0u) __builtin_trap();
+        __syncthreads();
+        uint32_t *b = reinterpret_cast<uint32_t *>(lds);
+        if (threadIdx.x < W) b[(size_t)'\n' * W + threadIdx.x] = threadIdx.x == 0 ? 1u : 0u;      // B['\n'] = {initial}
+    }
     __device__ __forceinline__ State fresh() const {
         State st;
 #pragma unroll
-        for (int i = 0; i < W; i++) st.s[i] = this->m.init[i];
+        for (int i = 0; i < W; i++) st.s[i] = i == 0 ? 1u : 0u;
         return st;
     }
     __device__ __forceinline__ State skipping() const {
@@ -227,22 +260,113 @@ struct LineNfaEngine : NfaCore<W> {
         for (int i = 0; i < W; i++) st.s[i] = 0;
         return st;
     }
+    __device__ __forceinline__ void advance_line(State &st, uint32_t c) const { advance_row(st, this->B + c * W); }
+    __device__ __forceinline__ void advance_row(State &st, const uint32_t *bc) const {
+        uint32_t t[W];
+        t[0] = (st.s[0] << 1) | 1u;
+#pragma unroll
+        for (int i = 1; i < W; i++) t[i] = __builtin_amdgcn_alignbit(st.s[i], st.s[i - 1], 31);
+        if (SELF) {
+#pragma unroll
+            for (int i = 0; i < W; i++) t[i] |= st.s[i] & this->m.self[i];
+        }
+        if (RULES) {
+            if (this->any_carry) {                               // ((S & CGRP) + CGRP) & CTGT as one multiword add
+                uint32_t cy = 0;
+#pragma unroll
+                for (int i = 0; i < W; i++) {
+                    const uint64_t sum = (uint64_t)(st.s[i] & this->m.cgrp[i]) + this->m.cgrp[i] + cy;
+                    t[i] |= (uint32_t)sum & this->m.ctgt[i];
+                    cy = (uint32_t)(sum >> 32);
+                }
+            }
+            if (this->any_exc) {
+                uint32_t exc = 0;
+#pragma unroll
+                for (int i = 0; i < W; i++) exc |= st.s[i] & this->m.excm[i];
+                if (exc) {
+#pragma unroll
+                    for (int i = 0; i < W; i++) {
+                        uint32_t e = st.s[i] & this->m.excm[i];
+                        while (e) {
+                            const int b = __ffs(e) - 1;
+                            e &= e - 1;
+                            const uint32_t *row = this->X + (size_t)(32 * i + b) * W;
+#pragma unroll
+                            for (int j = 0; j < W; j++) t[j] |= row[j];
+                        }
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < W; i++) st.s[i] = t[i] & bc[i];
+    }
+    // Byte K of text word w.  Two SDWA instructions read the byte straight out of the text register: the LDS address of
+    // its B row (byte * row bytes; B is the first thing in LDS) and the lane mask "this byte is '\n'".  hipcc's own
+    // code for the plain C form was 13 VALU per byte at W = 1 (field extraction, and the verdict if-converted into every
+    // step).  The four B rows of a text word are requested before the first of the four dependent steps.
+    typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
+    struct Row { uint32_t b[W]; };
     template <int K>
-    __device__ __forceinline__ void consume(State &st, uint32_t w, uint32_t &bits) const {
-        uint32_t nl, acc;
-        step(st, (w >> (8 * K)) & 0xffu, nl, acc);
-        bits = (bits << nl) | acc;
+    __device__ __forceinline__ Row row_of(uint32_t w) const {
+        uint32_t off;
+        const uint32_t row_bytes = W * 4;
+#define RRX_NFA_ROW(SEL) asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:" SEL " src1_sel:DWORD" : "=v"(off) : "v"(w), "v"(row_bytes))
+        if constexpr (K == 0) RRX_NFA_ROW("BYTE_0");
+        if constexpr (K == 1) RRX_NFA_ROW("BYTE_1");
+        if constexpr (K == 2) RRX_NFA_ROW("BYTE_2");
+        if constexpr (K == 3) RRX_NFA_ROW("BYTE_3");
+#undef RRX_NFA_ROW
+        const lds_u32_ptr p = reinterpret_cast<lds_u32_ptr>(off);    // B sits at LDS address 0 (checked in load)
+        Row r;
+#pragma unroll
+        for (int i = 0; i < W; i++) r.b[i] = p[i];
+        return r;
+    }
+    template <int K>
+    __device__ __forceinline__ void verdict(const State &st, uint32_t w, uint32_t &bits) const {
+        uint64_t nlmask;
+        const uint32_t ten = '\n';
+#define RRX_NFA_NL(SEL) asm("v_cmp_eq_u32_sdwa %0, %1, %2 src0_sel:" SEL " src1_sel:DWORD" : "=s"(nlmask) : "v"(w), "v"(ten))
+        if constexpr (K == 0) RRX_NFA_NL("BYTE_0");
+        if constexpr (K == 1) RRX_NFA_NL("BYTE_1");
+        if constexpr (K == 2) RRX_NFA_NL("BYTE_2");
+        if constexpr (K == 3) RRX_NFA_NL("BYTE_3");
+#undef RRX_NFA_NL
+        if (nlmask) {                                             // wave-uniform: some lane ends a line on this byte
+            uint32_t a = 0, tmp;
+#pragma unroll
+            for (int i = 0; i < W; i++) a |= st.s[i] & this->m.fin[i];
+            // bits = (bits << 1) | verdict on the lanes of nlmask: the verdict enters as the carry of bits + bits
+            asm volatile("v_cmp_ne_u32_e32 vcc, 0, %2\n\t"
+                         "v_addc_co_u32_e32 %1, vcc, %0, %0, vcc\n\t"
+                         "v_cndmask_b32_e64 %0, %0, %1, %3"
+                         : "+v"(bits), "=&v"(tmp) : "v"(a), "s"(nlmask) : "vcc");
+        }
+    }
+    __device__ __forceinline__ void consume_word(State &st, uint32_t w, uint32_t &bits) const {
+        if constexpr (W <= 4 && !RULES) {
+            const Row r0 = row_of<0>(w), r1 = row_of<1>(w), r2 = row_of<2>(w), r3 = row_of<3>(w);
+            verdict<0>(st, w, bits); advance_row(st, r0.b);
+            verdict<1>(st, w, bits); advance_row(st, r1.b);
+            verdict<2>(st, w, bits); advance_row(st, r2.b);
+            verdict<3>(st, w, bits); advance_row(st, r3.b);
+        } else {                                                  // wide sets: one row in flight ahead of the step
+            Row r = row_of<0>(w), n = row_of<1>(w);
+            verdict<0>(st, w, bits); advance_row(st, r.b);
+            r = row_of<2>(w);
+            verdict<1>(st, w, bits); advance_row(st, n.b);
+            n = row_of<3>(w);
+            verdict<2>(st, w, bits); advance_row(st, r.b);
+            verdict<3>(st, w, bits); advance_row(st, n.b);
+        }
     }
     __device__ __forceinline__ void step(State &st, uint32_t c, uint32_t &nl, uint32_t &acc) const {
         const bool isnl = c == '\n';
-        const bool a = this->accepting(st);
-        this->advance(st, c);                      // B['\n'] and B[0], B[>=0x80] are empty rows: the set dies
-        if (isnl) {
-#pragma unroll
-            for (int i = 0; i < W; i++) st.s[i] = this->m.init[i];
-        }
         nl = isnl ? 1u : 0u;
-        acc = (isnl && a) ? 1u : 0u;
+        acc = (isnl && this->accepting(st)) ? 1u : 0u;
+        advance_line(st, c);
     }
 };
 
@@ -315,6 +439,23 @@ __device__ __forceinline__ uint64_t line_of(uint64_t base) { return base & ~kFre
 // Text loads are plain loads: non-temporal ones stop the 8 loads of a 128-byte line from merging into one request
 // (measured -47 %, profiles/r01_v7_result_path_probes.txt).
 __device__ __forceinline__ uint4 load_text(const uint4 *p) { return *p; }
+
+// One round of a lane's text: N 16-byte slots requested as ONE burst (they merge into one request per 128-byte line)
+// and consumed in order.  The slots are members reached through compile-time recursion, never an indexed array: an
+// engine whose step contains a loop keeps the compiler from unrolling a slot loop, and an indexed buffer then lives in
+// scratch memory (measured on the first NFA engine: 144 bytes of scratch per lane, 18 ms per GiB).
+template <int N>
+struct TextRound {
+    uint4 head;
+    TextRound<N - 1> rest;
+    __device__ __forceinline__ void load(const uint4 *p) { head = load_text(p); rest.load(p + 1); }
+    template <class F> __device__ __forceinline__ void for_each_slot(F &&f) const { f(head); rest.for_each_slot(f); }
+};
+template <>
+struct TextRound<0> {
+    __device__ __forceinline__ void load(const uint4 *) {}
+    template <class F> __device__ __forceinline__ void for_each_slot(F &&) const {}
+};
 
 // ============================================================================================ batch kernel
 // Line verdicts of one lane.  `bits` = sentinel 1 followed by one verdict bit per line finished since the
@@ -413,36 +554,26 @@ __device__ __forceinline__ void match_stripes_body(const Program &prog, const ui
     // a register double buffer (94 VGPRs), two half-line bursts, a software-prefetch touch.
     size_t pos = start;
     const uint4 *src = reinterpret_cast<const uint4 *>(bytes + start);
-    constexpr int kSlots = kRound / 16;
-    const int rounds = (int)((my_end - start) / kRound);
-    uint4 buf[kSlots];
-    if (rounds > 0) {
-#pragma unroll
-        for (int i = 0; i < kSlots; i++) buf[i] = load_text(src + i);
-    }
+    // Engines with many words per set take half a line per round: their registers go to the state set, and they are
+    // bound by the VALU, not by the second fetch of a line's other half.
+    constexpr int kSlots = Engine::kRoundBytes / 16;
+    const int rounds = (int)((my_end - start) / Engine::kRoundBytes);
+    TextRound<kSlots> buf;                                       // named slots: never indexed at run time
+    if (rounds > 0) buf.load(src);
     for (int r = 0; r < rounds; r++) {
+        buf.for_each_slot([&](const uint4 &v) {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int i = 0; i < kSlots; i++) {
-            const uint32_t w[4] = {buf[i].x, buf[i].y, buf[i].z, buf[i].w};
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                eng.template consume<0>(st, w[q], res.bits);
-                eng.template consume<1>(st, w[q], res.bits);
-                eng.template consume<2>(st, w[q], res.bits);
-                eng.template consume<3>(st, w[q], res.bits);
-            }
+            for (int q = 0; q < 4; q++) eng.consume_word(st, w[q], res.bits);
             if (res.bits >> 15) res.flush();                 // <= 16 more results fit before the next check
-        }
-        // All lanes flush together every 4th round (512 bytes: ~11 lines of typical text fit the 31 result slots).
+        });
+        // All lanes flush together every 512 bytes (~11 lines of typical text fit the 31 result slots).
         // Every round costs 6 %; leaving it to the overflow check above makes the lanes flush at different
         // times, so that almost every check diverges: measured slower than either.
-        if ((r & 3) == 3) res.flush();
-        if (r + 1 < rounds) {
-#pragma unroll
-            for (int i = 0; i < kSlots; i++) buf[i] = load_text(src + (r + 1) * kSlots + i);
-        }
+        if ((r & (512 / Engine::kRoundBytes - 1)) == 512 / Engine::kRoundBytes - 1) res.flush();
+        if (r + 1 < rounds) buf.load(src + (size_t)(r + 1) * kSlots);
     }
-    pos += (size_t)rounds * kRound;
+    pos += (size_t)rounds * Engine::kRoundBytes;
 
     // ---- tail of the corpus inside my stripe (only the last stripe has one), byte by byte
     for (; pos < my_end; pos++) {
@@ -967,7 +1098,9 @@ template <class Engine, class Program>
 int launch_stripes(const Program &p, size_t table_bytes, const uint8_t *bytes, size_t nbytes, uint32_t stripe,
                    const uint64_t *stripe_base, size_t nstripes, uint32_t *accept, void *stream) {
     if (!nstripes) return 0;
-    auto k = Engine::kEightWaves ? match_stripes_kernel_8waves<Engine, Program> : match_stripes_kernel<Engine, Program>;
+    void (*k)(Program, const uint8_t *, size_t, uint32_t, const uint64_t *, uint32_t *, uint32_t, uint32_t);
+    if constexpr (Engine::kEightWaves) k = match_stripes_kernel_8waves<Engine, Program>;
+    else k = match_stripes_kernel<Engine, Program>;
     const uint32_t stage_off = (uint32_t)((table_bytes + 15) & ~(size_t)15);
     // the window takes what the tables leave of half a CU's LDS (two workgroups per CU), 16 KiB at least
     const size_t half_cu = 80 * 1024;
@@ -1210,9 +1343,12 @@ size_t scan_scratch_words(size_t n) { return (n + kScanChunk - 1) / kScanChunk +
 // The device tables are padded to the instantiated width by the caller (NfaDevice::W is the padded width).
 int match_stripes_nfa(const NfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
                       size_t nstripes, uint32_t *accept, void *stream) {
-#define CALL(WW) launch_stripes<LineNfaEngine<WW>, NfaDevice>(p, LineNfaEngine<WW>::lds_bytes(p), bytes, nbytes, stripe, stripe_base, nstripes, accept, stream)
+    // three builds per width: the bare chain, + self loops, + add-carry groups and exception rows
+#define GO(WW, S, R) launch_stripes<LineNfaEngine<WW, S, R>, NfaDevice>(p, LineNfaEngine<WW, S, R>::lds_bytes(p), bytes, nbytes, stripe, stripe_base, nstripes, accept, stream)
+#define CALL(WW) ((p.any_exc || p.any_carry) ? GO(WW, true, true) : p.any_self ? GO(WW, true, false) : GO(WW, false, false))
     RRX_NFA_DISPATCH(CALL)
 #undef CALL
+#undef GO
 }
 int match_stripes_dfa(const LineDfaDevice &p, bool clamp_high, const uint8_t *bytes, size_t nbytes, uint32_t stripe,
                       const uint64_t *stripe_base, size_t nstripes, uint32_t *accept, void *stream) {

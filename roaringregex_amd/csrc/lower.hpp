@@ -91,8 +91,9 @@ struct Reduced {
 };
 Reduced reduce(const Trimmed &t);
 
-// Returns false if the node count exceeds max_bits.
-bool lower_nfa(const Reduced &r, uint32_t max_bits, NfaProgram &out, bool allow_carry = true);
+// Returns false if the position count exceeds max_bits.  gaps: a never-entered position in front of every path head
+// but the first (the line-mode lane kernel shifts without a CHAIN mask).
+bool lower_nfa(const Reduced &r, uint32_t max_bits, NfaProgram &out, bool allow_carry = true, bool gaps = false);
 // Returns false if subset construction exceeds max_states.
 bool lower_dfa(const Reduced &r, uint32_t max_states, DfaProgram &out);
 

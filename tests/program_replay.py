@@ -37,6 +37,28 @@ class NfaReplay:
             S = t & self.B[c]
         return (S & self.fin) != 0
 
+    def match_lines(self, data):
+        """The LINE-MODE step of the batch kernel (kernels.hip: LineNfaEngine): no CHAIN mask (the lowering leaves a gap
+        position in front of every path head), a 1 shifted into position 0 on every byte, B['\\n'] = {position 0}, the
+        verdict S & FIN taken when the byte is '\\n'.  Returns one verdict per '\\n'-delimited line."""
+        assert self.init == 1
+        seq = bytes(data)
+        if seq and seq[-1] != 10:
+            seq += b"\n"                          # end of data ends the last line
+        out, S = [], self.init
+        for c in seq:
+            if c == 10:
+                out.append(1 if S & self.fin else 0)
+            t = ((S << 1) & self.mask) | 1 | (S & self.self_)
+            t |= ((S & self.cgrp) + self.cgrp) & self.ctgt
+            e = S & self.excm
+            while e:
+                b = (e & -e).bit_length() - 1
+                e &= e - 1
+                t |= self.X[b]
+            S = t & (1 if c == 10 else self.B[c])
+        return out
+
 
 class DfaReplay:
     def __init__(self, words):

@@ -116,6 +116,39 @@ def test_programs_keep_the_language_random():
     assert checked > 5000
 
 
+def test_line_mode_nfa_step_random():
+    """The batch kernel's NFA step as LineNfaEngine runs it (no CHAIN mask thanks to the gap positions, a 1 injected into
+    position 0 on every byte, B['\\n'] = {position 0}) replayed over whole corpora against the oracle."""
+    import numpy as np
+    rng = random.Random(29)
+    checked = 0
+    for _ in range(200):
+        p = random_pattern(rng)
+        try:
+            o = OracleRegex(p)
+        except OracleError:
+            continue
+        if o.states_n > 300:
+            continue
+        try:
+            r = rr.RRegex(p, rr.ENGINE_NFA)
+        except rr.RRegexError:
+            continue
+        rep = NfaReplay(r.program(rr.ENGINE_NFA))
+        lines = strings_near(rng, o) + ["", ""]
+        data = ("\n".join(lines) + ("\n" if rng.random() < 0.5 else "")).encode()
+        want = list(o.match_lines(np.frombuffer(data, dtype=np.uint8)))
+        assert rep.match_lines(data) == want, p
+        checked += len(want)
+    assert checked > 5000
+    for p in (U2, EMAIL, K1000_CONTAINS, "a{1,300}", "(a|b)*a(a|b){40}"):
+        o = OracleRegex(p)
+        rep = NfaReplay(rr.RRegex(p, rr.ENGINE_NFA).program(rr.ENGINE_NFA))
+        lines = ["http://example.com", "a@b", "a" * 300, "a" * 301, "x k17 y", "ab" * 30, "a" + "b" * 40, "", "https://a.b.cd:80/x?y#z"]
+        data = ("\n".join(lines)).encode()
+        assert rep.match_lines(data) == list(o.match_lines(np.frombuffer(data, dtype=np.uint8))), p[:20]
+
+
 def test_programs_keep_the_language_configs():
     rng = random.Random(3)
     cases = {
