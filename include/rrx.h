@@ -28,8 +28,10 @@ enum { RRX_OK = 0, RRX_ERR_PATTERN = 1, RRX_ERR_ARG = 2, RRX_ERR_HIP = 3, RRX_ER
 
 /* engine selection for rrx_compile_ex */
 enum { RRX_ENGINE_AUTO = 0, RRX_ENGINE_NFA = 1, RRX_ENGINE_DFA = 2, RRX_ENGINE_DFA_GLOBAL = 3 /* table kept in HBM/L2 */,
-       RRX_ENGINE_NFA_WAVE = 4 /* state set spread over the 64 lanes of a wave: up to 4096 positions */,
-       RRX_ENGINE_DFA2 = 5 /* table with one dependent lookup per two bytes (AUTO prefers it when it fits) */ };
+       RRX_ENGINE_NFA_WAVE = 4 /* state set spread over 16, 32 or 64 lanes of a wave: up to 4096 positions */,
+       RRX_ENGINE_DFA2 = 5 /* table with one dependent lookup per two bytes (AUTO prefers it when it fits) */,
+       RRX_ENGINE_NFA_BLOCK = 8 /* state set spread over a whole workgroup: up to 65536 positions, exception edges as
+                                   sparse lists (the reference's Roaring class, Parser.cpp:165, at any size) */ };
 
 /* ---- compile: RRegex::RRegex(const char*), Parser.cpp:161-170 (host only, no device needed) ---------- */
 int rrx_compile(const char *pattern, rrx_regex **out);
@@ -53,8 +55,9 @@ uint32_t    rrx_byte_classes(const rrx_regex *re);
 uint32_t    rrx_words_per_set(const rrx_regex *re); /* 32-bit words of the register-resident state set (NFA) */
 int         rrx_accepts_empty(const rrx_regex *re); /* Processor::operator*() on the initial set, NFA.cc:103-107 */
 /* Serialised device program as 32-bit words (layout: DESIGN.md "Device programs"); returns the word count
- * (call with cap = 0 to size the buffer).  kind = RRX_ENGINE_NFA / _DFA / _NFA_WAVE / _DFA2, or one of the two
- * search tables below (DFA layout); 0 if that form was not built.                                            */
+ * (call with cap = 0 to size the buffer).  kind = RRX_ENGINE_NFA / _DFA / _NFA_WAVE / _DFA2 / _NFA_BLOCK (NFA layout with
+ * the exception rows replaced by the CSR arrays xoff[nbits+1], xtgt[]), or one of the two search tables below (DFA
+ * layout); 0 if that form was not built.                                                                      */
 #define RRX_PROGRAM_SEARCH_FWD 6   /* "any bytes, then the pattern": accepting where a match ends              */
 #define RRX_PROGRAM_SEARCH_REV 7   /* the pattern right to left: accepting where a match starts                */
 size_t rrx_program_words(const rrx_regex *re, int kind, uint32_t *out, size_t cap);

@@ -32,8 +32,9 @@ struct DeviceTables {
     dev::NfaDevice nfa;
     dev::DfaDevice dfa;          // plain form (extents kernel)
     dev::LineDfaDevice line;     // line-mode form (batch kernel)
-    dev::WaveNfaDevice wave;     // wave-cooperative NFA
+    dev::GroupNfaDevice group;   // group-cooperative NFA (16/32/64 lanes per string)
     dev::Dfa2Device dfa2;        // stride-2 line-mode table (corpora without bytes >= 0x80)
+    dev::BlockNfaDevice block;   // block-cooperative NFA (up to 65536 positions)
 };
 
 struct SearchTablesOnDevice {
@@ -53,6 +54,8 @@ struct rrx_regex {
     NfaProgram nfa;
     NfaProgram nfa_wave;         // up to 4096 positions, no carry groups (wave-cooperative engine)
     bool has_wave = false;
+    NfaProgram nfa_block;        // up to 65536 positions, exception edges in CSR form (block-cooperative engine)
+    bool has_block = false;
     DfaProgram dfa;
     Dfa2Program dfa2;
     bool has_dfa2 = false;
@@ -138,17 +141,60 @@ struct rrx_regex {
         auto put = [&](const void *p, size_t n) { size_t off = (host.size() + 15) & ~(size_t)15; host.resize(off + n); std::memcpy(host.data() + off, p, n); return off; };
         size_t oB = 0, oX = 0, oC = 0, oN = 0, oA = 0, oT = 0, oL = 0, oP2 = 0, oT2 = 0;
         size_t oM = 0;
-        if (engine == RRX_ENGINE_NFA_WAVE) {
-            const uint32_t W = nfa_wave.W, WP = dev::kWaveWords;
-            std::vector<uint32_t> M((size_t)5 * WP, 0), B((size_t)256 * WP, 0), X((size_t)nfa_wave.nbits * WP, 0);
-            const std::vector<uint32_t> *src[5] = {&nfa_wave.init, &nfa_wave.fin, &nfa_wave.chain, &nfa_wave.self, &nfa_wave.excm};
-            for (int k = 0; k < 5; k++) for (uint32_t w = 0; w < W; w++) M[(size_t)k * WP + w] = (*src[k])[w];
-            for (uint32_t c = 0; c < 256; c++) for (uint32_t w = 0; w < W; w++) B[(size_t)c * WP + w] = nfa_wave.B[(size_t)c * W + w];
-            for (uint32_t b = 0; b < nfa_wave.nbits; b++) for (uint32_t w = 0; w < W; w++) X[(size_t)b * WP + w] = nfa_wave.X[(size_t)b * W + w];
+        size_t oCL = 0, oCP = 0, oXI = 0, oXO = 0, oXT = 0;
+        if (engine == RRX_ENGINE_NFA_BLOCK) {
+            // block-cooperative form: T lanes x 64 positions, class rows like the group form, exception edges as CSR
+            const uint32_t W = nfa_block.W, N = nfa_block.nbits;
+            uint32_t T = 256;
+            while (T * 64 < N) T *= 2;
+            const uint32_t WP = 2 * T, K = trimmed.ncls + 1;
+            std::vector<uint32_t> M((size_t)3 * WP, 0), B((size_t)K * WP, 0);
+            const std::vector<uint32_t> *src[3] = {&nfa_block.fin, &nfa_block.self, &nfa_block.excm};
+            for (int k = 0; k < 3; k++) for (uint32_t w = 0; w < W; w++) M[(size_t)k * WP + w] = (*src[k])[w];
+            for (uint32_t k = 1; k < trimmed.ncls; k++)
+                for (uint32_t w = 0; w < W; w++) B[(size_t)k * WP + w] = nfa_block.B[(size_t)trimmed.cls_rep[k] * W + w];
+            B[(size_t)(K - 1) * WP] = 1u;
+            uint8_t cl[256], cp[256];
+            for (int c = 0; c < 256; c++) cl[c] = cp[c] = trimmed.cls[c];
+            cl['\n'] = (uint8_t)(K - 1);
+            std::vector<uint32_t> xt = nfa_block.xtgt;
+            if (xt.empty()) xt.push_back(0);
+            oM = put(M.data(), M.size() * 4);
+            oB = put(B.data(), B.size() * 4);
+            oCL = put(cl, 256); oCP = put(cp, 256);
+            oXO = put(nfa_block.xoff.data(), nfa_block.xoff.size() * 4);
+            oXT = put(xt.data(), xt.size() * 4);
+            t.block.T = T; t.block.nbits = N; t.block.ncls = K; t.block.any_exc = nfa_block.n_exc ? 1 : 0;
+        } else if (engine == RRX_ENGINE_NFA_WAVE) {
+            // group-cooperative form: G lanes x 64 positions; B rows per byte CLASS (+ the line-mode '\n' row, last)
+            const uint32_t W = nfa_wave.W, N = nfa_wave.nbits;
+            const uint32_t G = N <= 1024 ? 16 : N <= 2048 ? 32 : 64, WP = 2 * G;
+            const uint32_t K = trimmed.ncls + 1;                         // classes of the automaton + the '\n' row
+            std::vector<uint32_t> M((size_t)3 * WP, 0), B((size_t)K * WP, 0);
+            const std::vector<uint32_t> *src[3] = {&nfa_wave.fin, &nfa_wave.self, &nfa_wave.excm};
+            for (int k = 0; k < 3; k++) for (uint32_t w = 0; w < W; w++) M[(size_t)k * WP + w] = (*src[k])[w];
+            for (uint32_t k = 1; k < trimmed.ncls; k++)                   // class 0 stays empty: nothing moves on it
+                for (uint32_t w = 0; w < W; w++) B[(size_t)k * WP + w] = nfa_wave.B[(size_t)trimmed.cls_rep[k] * W + w];
+            B[(size_t)(K - 1) * WP] = 1u;                                 // '\n' in line mode: {position 0}
+            uint8_t cl[256], cp[256];
+            for (int c = 0; c < 256; c++) cl[c] = cp[c] = trimmed.cls[c];
+            cl['\n'] = (uint8_t)(K - 1);
+            std::vector<uint16_t> xidx(N, 0xffff);
+            std::vector<uint32_t> X;
+            uint32_t rows = 0;
+            for (uint32_t b = 0; b < N; b++) {
+                if (!((nfa_wave.excm[b >> 5] >> (b & 31)) & 1u)) continue;
+                xidx[b] = (uint16_t)rows++;
+                X.resize((size_t)rows * WP, 0);
+                for (uint32_t w = 0; w < W; w++) X[(size_t)(rows - 1) * WP + w] = nfa_wave.X[(size_t)b * W + w];
+            }
+            if (X.empty()) X.assign(WP, 0);
             oM = put(M.data(), M.size() * 4);
             oB = put(B.data(), B.size() * 4);
             oX = put(X.data(), X.size() * 4);
-            t.wave.nbits = nfa_wave.nbits; t.wave.any_exc = nfa_wave.n_exc ? 1 : 0;
+            oCL = put(cl, 256); oCP = put(cp, 256);
+            oXI = put(xidx.data(), xidx.size() * 2);
+            t.group.G = G; t.group.nbits = N; t.group.ncls = K; t.group.n_exc = rows;
         } else if (engine == RRX_ENGINE_NFA) {
             const uint32_t W = nfa.W, WP = (uint32_t)instantiated_width(W);
             std::vector<uint32_t> B((size_t)256 * WP, 0), X((size_t)nfa.nbits * WP, 0);
@@ -238,10 +284,18 @@ struct rrx_regex {
             if (up != hipSuccess) { (void)hipFree(t.blob); return hip_fail(up, "device program upload"); }
         }
         const uint8_t *base = static_cast<const uint8_t *>(t.blob);
-        if (engine == RRX_ENGINE_NFA_WAVE) {
-            t.wave.masks = reinterpret_cast<const uint32_t *>(base + oM);
-            t.wave.B = reinterpret_cast<const uint32_t *>(base + oB);
-            t.wave.X = reinterpret_cast<const uint32_t *>(base + oX);
+        if (engine == RRX_ENGINE_NFA_BLOCK) {
+            t.block.masks = reinterpret_cast<const uint32_t *>(base + oM);
+            t.block.Bcls = reinterpret_cast<const uint32_t *>(base + oB);
+            t.block.cls_line = base + oCL; t.block.cls_plain = base + oCP;
+            t.block.xoff = reinterpret_cast<const uint32_t *>(base + oXO);
+            t.block.xtgt = reinterpret_cast<const uint32_t *>(base + oXT);
+        } else if (engine == RRX_ENGINE_NFA_WAVE) {
+            t.group.masks = reinterpret_cast<const uint32_t *>(base + oM);
+            t.group.Bcls = reinterpret_cast<const uint32_t *>(base + oB);
+            t.group.X = reinterpret_cast<const uint32_t *>(base + oX);
+            t.group.cls_line = base + oCL; t.group.cls_plain = base + oCP;
+            t.group.xidx = reinterpret_cast<const uint16_t *>(base + oXI);
         } else if (engine == RRX_ENGINE_NFA) {
             t.nfa.B = reinterpret_cast<const uint32_t *>(base + oB);
             t.nfa.X = reinterpret_cast<const uint32_t *>(base + oX);
@@ -283,7 +337,7 @@ const char *rrx_last_error(void) { return g_err.c_str(); }
 
 int rrx_compile_ex(const char *pattern, int engine, rrx_regex **out) {
     if (!pattern || !out) return fail(RRX_ERR_ARG, "null argument");
-    if (engine < RRX_ENGINE_AUTO || engine > RRX_ENGINE_DFA2) return fail(RRX_ERR_ARG, "unknown engine");
+    if (engine < RRX_ENGINE_AUTO || (engine > RRX_ENGINE_DFA2 && engine != RRX_ENGINE_NFA_BLOCK)) return fail(RRX_ERR_ARG, "unknown engine");
     *out = nullptr;
     rrx_regex *re = new rrx_regex();
     try {
@@ -292,7 +346,7 @@ int rrx_compile_ex(const char *pattern, int engine, rrx_regex **out) {
         re->trimmed = trim(re->ref);
         const Reduced red = reduce(re->trimmed);
         if (engine == RRX_ENGINE_AUTO || engine == RRX_ENGINE_NFA) re->has_nfa = lower_nfa(red, dev::kMaxNfaWords * 32, re->nfa, /*allow_carry=*/true, /*gaps=*/true);
-        if (engine != RRX_ENGINE_NFA && engine != RRX_ENGINE_NFA_WAVE) {     // (DFA, DFA_GLOBAL, DFA2, AUTO)
+        if (engine != RRX_ENGINE_NFA && engine != RRX_ENGINE_NFA_WAVE && engine != RRX_ENGINE_NFA_BLOCK) {     // (DFA, DFA_GLOBAL, DFA2, AUTO)
             re->has_dfa = lower_dfa(red, kMaxSubsetStates, re->dfa);
             if (re->has_dfa) {
                 re->line_wide = re->dfa.nstates <= dev::kWideMaxStates && engine != RRX_ENGINE_DFA_GLOBAL;
@@ -308,7 +362,10 @@ int rrx_compile_ex(const char *pattern, int engine, rrx_regex **out) {
         }
         // the wave-cooperative form: when asked for, or as the last resort of AUTO
         if (engine == RRX_ENGINE_NFA_WAVE || (engine == RRX_ENGINE_AUTO && !re->has_nfa && !re->has_dfa))
-            re->has_wave = lower_nfa(red, dev::kWaveWords * 32, re->nfa_wave, /*allow_carry=*/false);
+            re->has_wave = lower_nfa(red, dev::kGroupMaxBits, re->nfa_wave, /*allow_carry=*/false, /*gaps=*/true);
+        // the block-cooperative form (any automaton up to 65536 positions): when asked for, or when nothing else took it
+        if (engine == RRX_ENGINE_NFA_BLOCK || (engine == RRX_ENGINE_AUTO && !re->has_nfa && !re->has_dfa && !re->has_wave))
+            re->has_block = lower_nfa(red, dev::kBlockMaxBits, re->nfa_block, /*allow_carry=*/false, /*gaps=*/true);
     } catch (const PatternError &e) {
         delete re;
         return fail(RRX_ERR_PATTERN, e.what());
@@ -320,9 +377,10 @@ int rrx_compile_ex(const char *pattern, int engine, rrx_regex **out) {
     if (engine == RRX_ENGINE_NFA) re->engine = re->has_nfa ? RRX_ENGINE_NFA : 0;
     else if (engine == RRX_ENGINE_DFA || engine == RRX_ENGINE_DFA_GLOBAL) re->engine = re->has_dfa ? RRX_ENGINE_DFA : 0;
     else if (engine == RRX_ENGINE_NFA_WAVE) re->engine = re->has_wave ? RRX_ENGINE_NFA_WAVE : 0;
+    else if (engine == RRX_ENGINE_NFA_BLOCK) re->engine = re->has_block ? RRX_ENGINE_NFA_BLOCK : 0;
     else if (engine == RRX_ENGINE_DFA2) re->engine = re->has_dfa2 ? RRX_ENGINE_DFA : 0;
     else re->engine = (re->has_dfa && !re->line_global) ? RRX_ENGINE_DFA : re->has_nfa ? RRX_ENGINE_NFA : re->has_dfa ? RRX_ENGINE_DFA
-                      : re->has_wave ? RRX_ENGINE_NFA_WAVE : 0;
+                      : re->has_wave ? RRX_ENGINE_NFA_WAVE : re->has_block ? RRX_ENGINE_NFA_BLOCK : 0;
     if (!re->engine) {
         char msg[200];
         std::snprintf(msg, sizeof msg, "automaton too large for the requested engine (%u useful states)", re->trimmed.n);
@@ -346,15 +404,18 @@ uint32_t rrx_ref_row(const rrx_regex *re, uint32_t state, unsigned c, uint32_t *
 }
 int rrx_engine(const rrx_regex *re) { return re->engine; }
 const char *rrx_engine_name(const rrx_regex *re) {
-    if (re->engine == RRX_ENGINE_NFA_WAVE) return "nfa-wave-cooperative";
+    if (re->engine == RRX_ENGINE_NFA_WAVE) return "nfa-group-cooperative";
+    if (re->engine == RRX_ENGINE_NFA_BLOCK) return "nfa-block-cooperative";
     if (re->engine != RRX_ENGINE_DFA) return "nfa-shift-and";
     if (re->has_dfa2) return "dfa-stride2-table";      // (the byte-stride table still serves corpora with bytes >= 0x80)
     return re->line_global ? "dfa-global-table" : re->line_wide ? "dfa-wide-table" : "dfa-classed-table";
 }
 uint32_t rrx_useful_states(const rrx_regex *re) { return re->trimmed.n; }
 uint32_t rrx_byte_classes(const rrx_regex *re) { return re->trimmed.ncls; }
-uint32_t rrx_words_per_set(const rrx_regex *re) { return re->has_nfa ? re->nfa.W : re->has_wave ? re->nfa_wave.W : 0; }
-int rrx_accepts_empty(const rrx_regex *re) { return re->has_nfa ? re->nfa.accepts_empty : re->has_wave ? re->nfa_wave.accepts_empty : re->dfa.accepts_empty; }
+uint32_t rrx_words_per_set(const rrx_regex *re) { return re->has_nfa ? re->nfa.W : re->has_wave ? re->nfa_wave.W : re->has_block ? re->nfa_block.W : 0; }
+int rrx_accepts_empty(const rrx_regex *re) {
+    return re->has_nfa ? re->nfa.accepts_empty : re->has_wave ? re->nfa_wave.accepts_empty : re->has_block ? re->nfa_block.accepts_empty : re->dfa.accepts_empty;
+}
 
 size_t rrx_program_words(const rrx_regex *re, int kind, uint32_t *out, size_t cap) {
     std::vector<uint32_t> w;
@@ -362,6 +423,10 @@ size_t rrx_program_words(const rrx_regex *re, int kind, uint32_t *out, size_t ca
         const NfaProgram &p = kind == RRX_ENGINE_NFA ? re->nfa : re->nfa_wave;
         w = {p.W, p.nbits, p.n_exc, p.accepts_empty ? 1u : 0u};
         for (auto *v : {&p.init, &p.fin, &p.chain, &p.self, &p.excm, &p.cgrp, &p.ctgt, &p.B, &p.X}) w.insert(w.end(), v->begin(), v->end());
+    } else if (kind == RRX_ENGINE_NFA_BLOCK && re->has_block) {
+        const NfaProgram &p = re->nfa_block;
+        w = {p.W, p.nbits, p.n_exc, p.accepts_empty ? 1u : 0u};
+        for (auto *v : {&p.init, &p.fin, &p.chain, &p.self, &p.excm, &p.cgrp, &p.ctgt, &p.B, &p.xoff, &p.xtgt}) w.insert(w.end(), v->begin(), v->end());
     } else if (kind == RRX_ENGINE_DFA2 && re->has_dfa2) {
         const Dfa2Program &d = re->dfa2;
         w = {d.nstates, d.ncols, d.start, d.accepts_empty ? 1u : 0u};
@@ -456,8 +521,10 @@ int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accep
     if (!c->nlines) return RRX_OK;
     // the kernel merges words with atomic OR: start from an all-zero bitmap
     HIP_TRY(hipMemsetAsync(d_accept_bits, 0, rrx_corpus_bitmap_words(c) * sizeof(uint32_t), (hipStream_t)stream));
-    int e = re->engine == RRX_ENGINE_NFA_WAVE
-                ? dev::match_stripes_wave_nfa(t->wave, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream)
+    int e = re->engine == RRX_ENGINE_NFA_BLOCK
+                ? dev::match_stripes_block_nfa(t->block, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream)
+            : re->engine == RRX_ENGINE_NFA_WAVE
+                ? dev::match_stripes_group_nfa(t->group, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream)
             : re->engine == RRX_ENGINE_NFA
                 ? dev::match_stripes_nfa(t->nfa, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream)
             : (re->has_dfa2 && !c->has_high)
@@ -547,7 +614,8 @@ int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, cons
     if (rc) return rc;
     HIP_TRY(hipSetDevice(device));
     const uint8_t *b = static_cast<const uint8_t *>(d_bytes);
-    int e = re->engine == RRX_ENGINE_NFA_WAVE ? dev::match_extents_wave_nfa(t->wave, b, d_off, nitems, trim, d_accept, stream)
+    int e = re->engine == RRX_ENGINE_NFA_BLOCK ? dev::match_extents_block_nfa(t->block, b, d_off, nitems, trim, d_accept, stream)
+            : re->engine == RRX_ENGINE_NFA_WAVE ? dev::match_extents_group_nfa(t->group, b, d_off, nitems, trim, d_accept, stream)
             : re->engine == RRX_ENGINE_NFA ? dev::match_extents_nfa(t->nfa, b, d_off, nitems, trim, d_accept, stream)
                                          : dev::match_extents_dfa(t->dfa, b, d_off, nitems, trim, d_accept, stream);
     if (e) return hip_fail((hipError_t)e, "match_extents launch");
@@ -559,7 +627,7 @@ int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, cons
 // `scratch`/`scratch_bytes`: caller-provided device memory (rrx_match_cstr passes the tail of its own buffer).
 static int match_string_with(const rrx_regex *re, int device, const DeviceTables *t, const uint8_t *d_bytes, size_t nbytes, uint8_t *d_accept,
                              uint8_t *scratch, hipStream_t st) {
-    const bool table_engine = re->engine != RRX_ENGINE_NFA && re->engine != RRX_ENGINE_NFA_WAVE;
+    const bool table_engine = re->engine == RRX_ENGINE_DFA;
     if (table_engine && nbytes >= kLongStringBytes && t->dfa.nstates && t->dfa.nstates <= dev::kLongMaxStates) {
         uint32_t chunk = 0;
         (void)dev::long_scratch_bytes(t->dfa.nstates, nbytes, &chunk);
@@ -575,7 +643,7 @@ static int match_string_with(const rrx_regex *re, int device, const DeviceTables
     return rrx_match_extents(re, device, d_bytes, d_off, 1, 0, d_accept, st);
 }
 static size_t match_string_scratch_bytes(const rrx_regex *re, const DeviceTables *t, size_t nbytes) {
-    const bool table_engine = re->engine != RRX_ENGINE_NFA && re->engine != RRX_ENGINE_NFA_WAVE;
+    const bool table_engine = re->engine == RRX_ENGINE_DFA;
     if (table_engine && nbytes >= kLongStringBytes && t->dfa.nstates && t->dfa.nstates <= dev::kLongMaxStates) {
         uint32_t chunk = 0;
         return dev::long_scratch_bytes(t->dfa.nstates, nbytes, &chunk);

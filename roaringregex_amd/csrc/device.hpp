@@ -42,14 +42,32 @@ struct NfaDevice {                               // tables in HBM (copied to LDS
     const uint32_t *X = nullptr;                 // [nbits][W]
 };
 
-// Wave-cooperative NFA (automata beyond kMaxNfaWords*32 positions): the state set is spread over the 64 lanes
-// of a wave, one 64-bit word per lane (4096 positions); every table row is kWaveWords 32-bit words in HBM/L2.
-constexpr uint32_t kWaveWords = 128;
-struct WaveNfaDevice {
-    uint32_t nbits = 0, any_exc = 0;
-    const uint32_t *masks = nullptr;             // [5][kWaveWords]: init, fin, chain, self, excm
-    const uint32_t *B = nullptr;                 // [256][kWaveWords]
-    const uint32_t *X = nullptr;                 // [nbits][kWaveWords]
+// Group-cooperative NFA (automata beyond kMaxNfaWords*32 positions): the state set is spread over G = 16, 32 or 64
+// neighbouring lanes of a wave, one 64-bit word per lane (1024 / 2048 / 4096 positions); a wave steps 64 / G strings.
+constexpr uint32_t kGroupMaxBits = 4096;
+constexpr size_t kGroupLdsBudget = 64 * 1024;    // class rows of the B table
+struct GroupNfaDevice {
+    uint32_t G = 0, nbits = 0, ncls = 0, n_exc = 0;
+    const uint32_t *masks = nullptr;             // [3][G][2]: fin, self, excm
+    const uint32_t *Bcls = nullptr;              // [ncls][G][2]: positions enterable on a byte of the class; class 0 = no
+                                                 //   position (0x00, >= 0x80, bytes outside every label), class ncls-1 = the
+                                                 //   line-mode '\n' row {position 0}
+    const uint8_t *cls_line = nullptr;           // [256] byte -> class, '\n' -> ncls-1 (batch kernel)
+    const uint8_t *cls_plain = nullptr;          // [256] byte -> class, '\n' an ordinary byte (extents kernel)
+    const uint16_t *xidx = nullptr;              // [nbits] exception row of a position (0xffff: none)
+    const uint32_t *X = nullptr;                 // [n_exc][G][2]
+};
+
+// Block-cooperative NFA (automata beyond kGroupMaxBits positions): one WORKGROUP of T lanes holds one state set, 64
+// positions per lane (T = 256 ... 1024: up to 65536 positions); exception edges are CSR lists, not rows.
+constexpr uint32_t kBlockMaxBits = 65536;
+struct BlockNfaDevice {
+    uint32_t T = 0, nbits = 0, ncls = 0, any_exc = 0;
+    const uint32_t *masks = nullptr;             // [3][T][2]: fin, self, excm
+    const uint32_t *Bcls = nullptr;              // [ncls][T][2], classes as in GroupNfaDevice
+    const uint8_t *cls_line = nullptr, *cls_plain = nullptr;
+    const uint32_t *xoff = nullptr;              // [nbits + 1]
+    const uint32_t *xtgt = nullptr;              // targets of position p: xtgt[xoff[p] .. xoff[p+1])
 };
 
 // Plain DFA (extents kernel: '\n' is an ordinary byte).
@@ -113,10 +131,14 @@ int match_stripes_nfa(const NfaDevice &p, const uint8_t *bytes, size_t nbytes, u
 int match_stripes_dfa(const LineDfaDevice &p, bool clamp_high, const uint8_t *bytes, size_t nbytes, uint32_t stripe,
                       const uint64_t *stripe_base, size_t nstripes, uint32_t *accept_bits, void *stream);
 
-int match_stripes_wave_nfa(const WaveNfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
-                           size_t nstripes, uint32_t *accept_bits, void *stream);
-int match_extents_wave_nfa(const WaveNfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim,
-                           uint8_t *accept, void *stream);
+int match_stripes_group_nfa(const GroupNfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
+                            size_t nstripes, uint32_t *accept_bits, void *stream);
+int match_extents_group_nfa(const GroupNfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim,
+                            uint8_t *accept, void *stream);
+int match_stripes_block_nfa(const BlockNfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
+                            size_t nstripes, uint32_t *accept_bits, void *stream);
+int match_extents_block_nfa(const BlockNfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim,
+                            uint8_t *accept, void *stream);
 
 // items i = bytes[off[i] .. off[i+1] - trim) ; trim = 1 drops a trailing delimiter byte per item
 // Search (the reference has acceptance only): two plain DFAs over the same byte classes.  fwd = "any bytes, then the

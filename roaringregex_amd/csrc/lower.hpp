@@ -41,6 +41,8 @@ struct Trimmed {
 
 Trimmed trim(const RefAutomaton &a);
 
+constexpr uint32_t kDenseExceptionBits = 4096;
+
 struct NfaProgram {
     uint32_t W = 0;                         // 32-bit words per state set
     uint32_t nbits = 0;                     // positions in use
@@ -49,7 +51,9 @@ struct NfaProgram {
     std::vector<uint32_t> init, fin, chain, self, excm;   // W words each
     std::vector<uint32_t> cgrp, ctgt;                     // W words each: carry groups and their targets
     uint32_t n_carry = 0;                                 // carry groups
-    std::vector<uint32_t> X;                // nbits rows of W words: extra successors of position p
+    std::vector<uint32_t> X;                // nbits rows of W words: extra successors of position p (dense form: only
+                                            //   up to kDenseExceptionBits positions)
+    std::vector<uint32_t> xoff, xtgt;       // the same in CSR form: targets of position p = xtgt[xoff[p] .. xoff[p+1])
     std::vector<uint32_t> B;                // 256 rows of W words: positions enterable on byte c
     bool accepts_empty = false;
 };

@@ -5,7 +5,8 @@ import numpy as np
 
 
 class NfaReplay:
-    def __init__(self, words):
+    def __init__(self, words, sparse=False):
+        """sparse: the block-cooperative program (kind 8): CSR arrays xoff[nbits+1], xtgt[] instead of dense rows"""
         w = [int(x) for x in words]
         self.W, self.nbits, self.n_exc, self.accepts_empty = w[0], w[1], w[2], bool(w[3])
         W, o = self.W, 4
@@ -19,7 +20,11 @@ class NfaReplay:
         o += 7 * W
         self.B = [big(w[o + c * W:o + (c + 1) * W]) for c in range(256)]
         o += 256 * W
-        self.X = [big(w[o + b * W:o + (b + 1) * W]) for b in range(self.nbits)]
+        if sparse:
+            xoff, xtgt = w[o:o + self.nbits + 1], w[o + self.nbits + 1:]
+            self.X = [sum(1 << q for q in xtgt[xoff[b]:xoff[b + 1]]) for b in range(self.nbits)]
+        else:
+            self.X = [big(w[o + b * W:o + (b + 1) * W]) for b in range(self.nbits)]
         self.mask = (1 << (32 * W)) - 1
 
     def accepts(self, s):

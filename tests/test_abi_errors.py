@@ -48,5 +48,5 @@ def test_engine_selection_ladder():
     assert rr.RRegex("abc", rr.ENGINE_DFA).engine_name == "dfa-wide-table"
     assert rr.RRegex("a{1,300}", rr.ENGINE_DFA).engine_name == "dfa-classed-table"
     assert rr.RRegex("(a|b)*a(a|b){40}").engine_name == "nfa-shift-and"           # 2^41 subsets, 44 positions
-    assert rr.RRegex("(a|b)*a(a|b){600}").engine_name == "nfa-wave-cooperative"
+    assert rr.RRegex("(a|b)*a(a|b){600}").engine_name == "nfa-group-cooperative"
     assert rr.RRegex("abc", rr.ENGINE_DFA_GLOBAL).engine_name == "dfa-global-table"

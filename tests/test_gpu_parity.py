@@ -22,10 +22,10 @@ def _need_gpu():
 
 
 def engines_for(pattern, small=False):
-    """One compiled regex per device engine that admits the automaton.  The wave-cooperative NFA runs one string
-    per wave (tens of MB/s), so it only joins on small inputs."""
+    """One compiled regex per device engine that admits the automaton.  The group- and block-cooperative NFAs are the
+    engines of big automata (a whole workgroup per string in the block form), so they only join on small inputs."""
     out = []
-    kinds = [rr.ENGINE_NFA, rr.ENGINE_DFA, rr.ENGINE_DFA2, rr.ENGINE_DFA_GLOBAL] + ([rr.ENGINE_NFA_WAVE] if small else [])
+    kinds = [rr.ENGINE_NFA, rr.ENGINE_DFA, rr.ENGINE_DFA2, rr.ENGINE_DFA_GLOBAL] + ([rr.ENGINE_NFA_WAVE, rr.ENGINE_NFA_BLOCK] if small else [])
     for e in kinds:
         try:
             out.append(rr.RRegex(pattern, e))
@@ -415,12 +415,12 @@ def test_large_global_table_automaton_through_every_entry_point():
 
 
 def test_wave_cooperative_engine_on_large_automata():
-    """Automata beyond 512 positions whose subset construction explodes (AUTO -> nfa-wave-cooperative), against the
+    """Automata beyond 512 positions whose subset construction explodes (AUTO -> nfa-group-cooperative), against the
     oracle: batch kernel at several stripe sizes, and the single-string entry."""
     rng = random.Random(77)
     p = "(a|b)*a(a|b){600}"
     r = rr.RRegex(p)
-    assert r.engine_name == "nfa-wave-cooperative"
+    assert r.engine_name == "nfa-group-cooperative"
     o = OracleRegex(p)
     lines = []
     for n in (0, 1, 600, 601, 602, 603, 700, 1300, 5000):
@@ -436,6 +436,32 @@ def test_wave_cooperative_engine_on_large_automata():
         got = r.match_corpus(rr.Corpus(dev, stripe=stripe)).cpu().numpy()
         assert (got == want).all(), stripe
     for t in lines[:12]:
+        assert (r.get_acceptance_iter(t).advance().value() is not None) == o.accepts(t)
+
+
+def test_block_cooperative_engine_beyond_4096_positions():
+    """An automaton with more than 4096 positions (5003: no table form exists, beyond the group engine) compiles to the
+    block-cooperative engine and matches the oracle: batch kernel, extents kernel, iterator facade."""
+    rng = random.Random(78)
+    p = "(a|b)*a(a|b){5000}"
+    r = rr.RRegex(p)
+    assert r.engine_name == "nfa-block-cooperative"
+    o = OracleRegex(p)
+    lines = ["", "a", "a" + "b" * 5000, "b" + "b" * 5000, "ab" * 100 + "a" + "a" * 5000, "a" * 4999, "a" * 5002]
+    for n in (5001, 5002, 5600, 9000):
+        lines.append("".join(rng.choice("ab") for _ in range(n)))
+    data = ("\n".join(lines)).encode()
+    want = o.match_lines(np.frombuffer(data, dtype=np.uint8))
+    assert 0 < want.sum() < len(want)
+    dev = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+    for stripe in (1024, 16384):
+        got = r.match_corpus(rr.Corpus(dev, stripe=stripe)).cpu().numpy()
+        assert (got == want).all(), stripe
+    off = np.cumsum([0] + [len(t) for t in lines]).astype(np.int64)
+    blob = torch.from_numpy(np.frombuffer("".join(lines).encode(), dtype=np.uint8).copy()).cuda()
+    got = r.match_extents(blob, torch.from_numpy(off).cuda()).cpu().numpy()
+    assert list(got) == [int(x) for x in want]
+    for t in lines[:5]:
         assert (r.get_acceptance_iter(t).advance().value() is not None) == o.accepts(t)
 
 

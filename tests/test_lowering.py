@@ -116,6 +116,32 @@ def test_programs_keep_the_language_random():
     assert checked > 5000
 
 
+def test_block_program_beyond_4096_positions():
+    """(a|b)*a(a|b){5000}: 5003 positions, no table form, beyond the group engine -> nfa-block-cooperative (the reference's
+    Roaring class at any size, Parser.cpp:165).  Its program (exception edges as CSR lists) replays to the oracle's
+    answers, in the plain and in the line-mode form; small automata forced onto the engine do too."""
+    import numpy as np
+    rng = random.Random(43)
+    p = "(a|b)*a(a|b){5000}"
+    r = rr.RRegex(p)
+    assert r.engine == rr.ENGINE_NFA_BLOCK and r.engine_name == "nfa-block-cooperative"
+    w = r.program(rr.ENGINE_NFA_BLOCK)
+    assert w[1] > 4096
+    rep = NfaReplay(w, sparse=True)
+    o = OracleRegex(p)
+    texts = ["", "a", "a" + "b" * 5000, "b" + "b" * 5000, "ab" * 100 + "a" + "a" * 5000, "a" * 4999, "a" * 5002]
+    texts.append("".join(rng.choice("ab") for _ in range(5600)))
+    for t in texts:
+        assert rep.accepts(t.encode()) == o.accepts(t), len(t)
+    data = ("\n".join(texts[:5])).encode()
+    assert rep.match_lines(data) == list(o.match_lines(np.frombuffer(data, dtype=np.uint8)))
+    for q in ("(ab|cd)+e?", "a{2,9}b", "[ab]*c[ab]{3}"):
+        rep = NfaReplay(rr.RRegex(q, rr.ENGINE_NFA_BLOCK).program(rr.ENGINE_NFA_BLOCK), sparse=True)
+        oq = OracleRegex(q)
+        for t in strings_near(rng, oq, alphabet="abcde"):
+            assert rep.accepts(t.encode()) == oq.accepts(t), (q, t)
+
+
 def test_line_mode_nfa_step_random():
     """The batch kernel's NFA step as LineNfaEngine runs it (no CHAIN mask thanks to the gap positions, a 1 injected into
     position 0 on every byte, B['\\n'] = {position 0}) replayed over whole corpora against the oracle."""
@@ -189,7 +215,7 @@ def test_wave_program_for_automata_beyond_one_lane():
         o = OracleRegex(p)
         r = rr.RRegex(p)
         if p.startswith("(a|b)"):
-            assert r.engine == rr.ENGINE_NFA_WAVE and r.engine_name == "nfa-wave-cooperative"
+            assert r.engine == rr.ENGINE_NFA_WAVE and r.engine_name == "nfa-group-cooperative"
         w = rr.RRegex(p, rr.ENGINE_NFA_WAVE).program(rr.ENGINE_NFA_WAVE)
         assert w is not None and w[1] > 512
         rep = NfaReplay(w)
