@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "rrx_engine", "rrx_engine_name", "rrx_useful_states", "rrx_byte_classes", "rrx_words_per_set", "rrx_accepts_empty",
     "rrx_program_words",
     "rrx_corpus_create", "rrx_corpus_create_ex", "rrx_corpus_stripe_bytes", "rrx_corpus_num_lines", "rrx_corpus_num_bytes", "rrx_corpus_free", "rrx_corpus_bitmap_words",
-    "rrx_match_corpus", "rrx_search_corpus", "rrx_search_all_count", "rrx_search_all_fill", "rrx_bitmap_to_bytes",
+    "rrx_match_corpus", "rrx_match_device", "rrx_search_corpus", "rrx_search_all_count", "rrx_search_all_fill", "rrx_bitmap_to_bytes",
     "rrx_match_extents", "rrx_match_string", "rrx_match_host", "rrx_match_cstr",
 )
 
@@ -72,6 +72,7 @@ def _load():
         "rrx_corpus_free": (None, [vp]),
         "rrx_corpus_bitmap_words": (sz, [vp]),
         "rrx_match_corpus": (i32, [vp, vp, vp, vp]),
+        "rrx_match_device": (i32, [vp, i32, vp, sz, vp, sz, C.POINTER(sz), vp]),
         "rrx_bitmap_to_bytes": (i32, [i32, vp, sz, vp, vp]),
         "rrx_match_extents": (i32, [vp, i32, vp, vp, sz, u32, vp, vp]),
         "rrx_match_string": (i32, [vp, i32, vp, sz, vp, vp]),
@@ -232,6 +233,25 @@ class RRegex:
             assert out.is_cuda and out.dtype == torch.int32 and out.numel() >= nw
             _check(_L.rrx_match_corpus(self._h, corpus._h, C.c_void_p(out.data_ptr() if nw else 0), _stream_ptr(stream)))
         return out[:nw]
+
+    def match_device_bits(self, data, cap_lines=None, out=None, stream=None):
+        """One-shot (rrx_match_device): a device tensor nobody has indexed -> (accept bitmap as int32 words, number of
+        strings).  With the stride-2 table engine the text is read once.  cap_lines bounds the number of strings the
+        bitmap can hold (default: one per 8 bytes, at least 1024)."""
+        import torch
+        assert data.is_cuda and data.dtype == torch.uint8 and data.is_contiguous()
+        n = data.numel()
+        if cap_lines is None:
+            cap_lines = n + 1
+        cap_words = (cap_lines + 31) // 32
+        with _on(data.device.index, stream):
+            if out is None:
+                out = torch.empty(cap_words, dtype=torch.int32, device=data.device)
+            assert out.is_cuda and out.dtype == torch.int32 and out.numel() >= cap_words
+            nlines = C.c_size_t(0)
+            _check(_L.rrx_match_device(self._h, data.device.index, C.c_void_p(data.data_ptr() if n else 0), n,
+                                       C.c_void_p(out.data_ptr()), cap_words, C.byref(nlines), _stream_ptr(stream)))
+        return out[:(nlines.value + 31) // 32], nlines.value
 
     def match_corpus(self, corpus, out=None, stream=None):
         """accept[i] = 1 iff line i of the corpus is accepted (one byte per line: bitmap + expansion)."""

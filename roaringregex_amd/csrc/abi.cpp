@@ -87,8 +87,24 @@ struct rrx_regex {
         return RRX_OK;
     }
 
+    // Scratch of the one-shot entry (rrx_match_device): per-stripe counts, their scan and the lanes' verdict streams.
+    mutable std::mutex onepass_mu;
+    mutable std::map<int, Scratch> onepass_scratch;
+    int onepass_for(int device, size_t bytes, void **out) const {      // call with `onepass_mu` held
+        Scratch &sc = onepass_scratch[device];
+        if (sc.cap < bytes) {
+            if (sc.p) { (void)hipFree(sc.p); sc.p = nullptr; sc.cap = 0; }
+            hipError_t e = hipMalloc(&sc.p, bytes);
+            if (e != hipSuccess) { sc.p = nullptr; return hip_fail(e, "hipMalloc(one-pass scratch)"); }
+            sc.cap = bytes;
+        }
+        *out = sc.p;
+        return RRX_OK;
+    }
+
     ~rrx_regex() {
         for (auto &kv : scratch) if (kv.second.p) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.p); }
+        for (auto &kv : onepass_scratch) if (kv.second.p) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.p); }
         for (auto &kv : on_device) if (kv.second.blob) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.blob); }
         for (auto &kv : search_on_device) if (kv.second.blob) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.blob); }
     }
@@ -531,6 +547,66 @@ int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accep
                 ? dev::match_stripes_dfa2(t->dfa2, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream)
                 : dev::match_stripes_dfa(t->line, c->has_high, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream);
     if (e) return hip_fail((hipError_t)e, "match_stripes launch");
+    return RRX_OK;
+}
+
+// One-shot entry: a device-resident buffer that nobody has indexed.  With the stride-2 table engine the text is read ONCE:
+// the match kernel counts the '\n' of every stripe on the side and leaves every lane's verdicts as a stream of its own;
+// a scan of the counts and a small compaction kernel then put the streams at their line numbers.  Other engines build
+// the index first (two passes).  Synchronous: *nlines is read back.
+int rrx_match_device(const rrx_regex *re, int device, const void *d_bytes, size_t nbytes, uint32_t *d_accept_bits, size_t cap_words,
+                     size_t *nlines, void *stream) {
+    if (!re || (nbytes && !d_bytes) || !nlines || (cap_words && !d_accept_bits)) return fail(RRX_ERR_ARG, "null argument");
+    if (reinterpret_cast<uintptr_t>(d_bytes) & 15) return fail(RRX_ERR_ARG, "corpus base must be 16-byte aligned");
+    *nlines = 0;
+    HIP_TRY(hipSetDevice(device));
+    if (!nbytes) return RRX_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!(re->engine == RRX_ENGINE_DFA && re->has_dfa2)) {                 // two passes: index, then match
+        rrx_corpus *c = nullptr;
+        int rc = rrx_corpus_create(device, d_bytes, nbytes, stream, &c);
+        if (rc) return rc;
+        *nlines = c->nlines;
+        if (rrx_corpus_bitmap_words(c) > cap_words) rc = fail(RRX_ERR_ARG, "accept bitmap too small for the number of strings");
+        if (!rc) rc = rrx_match_corpus(re, c, d_accept_bits, stream);
+        const hipError_t e = hipStreamSynchronize(st);                      // the index arrays of `c` are freed next
+        if (!rc && e != hipSuccess) rc = hip_fail(e, "match_device");
+        rrx_corpus_free(c);
+        return rc;
+    }
+    const DeviceTables *t;
+    int rc = re->tables(device, &t);
+    if (rc) return rc;
+    const uint8_t *bytes = static_cast<const uint8_t *>(d_bytes);
+    const uint32_t stripe = dev::pick_stripe(nbytes);
+    const size_t nstripes = (nbytes + stripe - 1) / stripe;
+    // scratch: [counts u32 (nstripes) | flag u32 | pad] [base u64 (nstripes + 1) + scan scratch] [slabs u32]
+    const size_t counts_bytes = ((nstripes + 2) * sizeof(uint32_t) + 15) & ~(size_t)15;
+    const size_t base_bytes = (nstripes + 1 + dev::scan_scratch_words(nstripes)) * sizeof(uint64_t);
+    const size_t slab_bytes = dev::onepass_slab_words(nstripes, stripe) * sizeof(uint32_t);
+    std::lock_guard<std::mutex> lock(re->onepass_mu);
+    void *buf = nullptr;
+    rc = re->onepass_for(device, counts_bytes + base_bytes + slab_bytes, &buf);
+    if (rc) return rc;
+    uint32_t *d_counts = static_cast<uint32_t *>(buf), *d_flag = d_counts + nstripes;
+    uint64_t *d_base = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(buf) + counts_bytes);
+    uint32_t *d_slabs = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(buf) + counts_bytes + base_bytes);
+    HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(uint32_t), st));
+    if (cap_words) HIP_TRY(hipMemsetAsync(d_accept_bits, 0, cap_words * sizeof(uint32_t), st));
+    int e = dev::match_onepass_dfa2(t->dfa2, bytes, nbytes, stripe, nstripes, d_counts, d_slabs, stream);
+    if (!e) e = dev::scan_counts(d_counts, d_base, d_base + nstripes + 1, nstripes, stream);
+    if (!e) e = dev::compact_streams(d_counts, d_base, nstripes, stripe, d_slabs, d_accept_bits, cap_words, d_flag, stream);
+    if (e) return hip_fail((hipError_t)e, "one-pass launch");
+    uint64_t total = 0;
+    uint32_t flag = 0;
+    uint8_t last = '\n';
+    hipError_t he = hipMemcpyAsync(&total, d_base + nstripes, sizeof total, hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess) he = hipMemcpyAsync(&flag, d_flag, sizeof flag, hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess) he = hipMemcpyAsync(&last, bytes + nbytes - 1, 1, hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    if (he != hipSuccess) return hip_fail(he, "one-pass readback");
+    *nlines = (size_t)total + (last != '\n' ? 1 : 0);
+    if (flag & 1u) return fail(RRX_ERR_ARG, "accept bitmap too small for the number of strings");
     return RRX_OK;
 }
 

@@ -119,6 +119,15 @@ constexpr uint32_t kDfa2TableBudget = 30 * 1024;                      // T2 with
 int match_stripes_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
                        size_t nstripes, uint32_t *accept_bits, void *stream);
 
+// One-pass mode (no line index yet): the stride-2 kernel writes counts[g] ('\n' per stripe, with flags) and every lane's
+// verdict stream into `slabs` (onepass_slab_words() words); after scan_counts, compact_streams moves the streams to their
+// place in the (zeroed) accept bitmap; *overflow gets bit 0 set if the bitmap is too small.
+size_t onepass_slab_words(size_t nstripes, uint32_t stripe);
+int match_onepass_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, size_t nstripes, uint32_t *counts,
+                       uint32_t *slabs, void *stream);
+int compact_streams(const uint32_t *counts, const uint64_t *stripe_base, size_t nstripes, uint32_t stripe, const uint32_t *slabs,
+                    uint32_t *accept_bits, size_t cap_words, uint32_t *overflow, void *stream);
+
 // All launchers are asynchronous on `stream` and return a hipError_t value (0 = success).
 int count_newlines_per_stripe(const uint8_t *bytes, size_t nbytes, uint32_t stripe, uint32_t *counts, size_t nstripes, uint32_t *flags, void *stream);
 int scan_counts(const uint32_t *counts, uint64_t *base, uint64_t *chunk_sums, size_t n, void *stream);   // base[n] = total

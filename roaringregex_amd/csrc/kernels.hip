@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <atomic>
+#include <type_traits>
 
 #include "device.hpp"
 
@@ -522,6 +523,45 @@ struct ResultsT {
 };
 typedef ResultsT<false> Results;
 
+// One-pass mode (rrx_match_device: no line index exists yet): a lane does not know the index of its first line, so it
+// packs its verdicts from bit 0 of its OWN stream and stores the stream word by word into the workgroup's slab in HBM,
+// slab[word][lane] (word k of the lanes of a workgroup is one contiguous row).  The per-stripe newline counts the lanes
+// write on the side are scanned afterwards, and compact_streams_kernel shifts every lane's stream to its place in the
+// accept bitmap.  bit k of a lane's stream = the k-th line end it saw (the first one belongs to the lane before if the
+// stripe starts inside a line: the compaction drops it, as ResultsT does with drop_first).
+struct LocalResults {
+    uint32_t bits = 1, outw = 0, fill = 0, seen = 0, k = 0;
+    uint32_t *__restrict__ dst;            // &slab[0][lane]
+    __device__ __forceinline__ void begin(uint32_t *slab_lane) { dst = slab_lane; }
+    __device__ __forceinline__ void push(uint32_t nl, uint32_t acc) { bits = (bits << nl) | acc; }
+    __device__ __forceinline__ void flush() {
+        const int n = 31 - __clz((int)bits);
+        if (n > 0) {
+            const uint32_t rev = __brev(bits & ((1u << n) - 1u)) >> (32 - n);      // oldest line at bit 0
+            outw |= rev << fill;
+            uint32_t nf = fill + (uint32_t)n;
+            if (nf >= 32u) {
+                dst[(size_t)k * kThreads] = outw;
+                k++;
+                outw = fill ? rev >> (32u - fill) : 0u;
+                nf -= 32u;
+            }
+            fill = nf;
+            seen += (uint32_t)n;
+            bits = 1;
+        }
+    }
+    __device__ __forceinline__ void finish() {
+        flush();
+        if (fill) dst[(size_t)k * kThreads] = outw;
+    }
+};
+constexpr uint32_t kCountMask = 0x3fffffffu;             // counts[g]: bits 0..29 = '\n' in stripe g
+constexpr uint32_t kExtraResult = 0x40000000u;           // bit 30 (one-pass mode): the lane's stream holds one result more than
+                                                         //   its stripe has '\n' (a line followed past the stripe end, or the
+                                                         //   last line of a corpus that does not end in '\n')
+__host__ __device__ inline size_t slab_words_per_lane(uint32_t stripe) { return stripe / 32 + 1; }
+
 template <class Engine, class Program>
 __device__ __forceinline__ void match_stripes_body(const Program &prog, const uint8_t *__restrict__ bytes, size_t nbytes,
                                                    uint32_t stripe, const uint64_t *__restrict__ stripe_base,
@@ -681,9 +721,14 @@ struct Dfa2 {
 
 // Same stripe geometry, feed and result path as match_stripes_kernel; pairs are aligned to even byte positions
 // (stripes are even-sized), a line end may fall on either byte of a pair.
-__global__ __launch_bounds__(kThreads) void match_stripes2_kernel(Dfa2Device prog, const uint8_t *__restrict__ bytes, size_t nbytes,
-                                                                   uint32_t stripe, const uint64_t *__restrict__ stripe_base,
-                                                                   uint32_t *__restrict__ accept_bits) {
+// ONEPASS (rrx_match_device): no line index yet.  Every lane starts in the start state (a lane that begins inside a line
+// produces a verdict for the fragment, which the compaction drops), counts its '\n' on the side, and keeps its verdict
+// stream in the workgroup's slab (LocalResults).  Bytes >= 0x80 cannot index the pair table: a text word that holds one is
+// rewritten with 0x00 in their place (which rejects the line just the same) under a wave-uniform branch.
+template <bool ONEPASS>
+__device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t *__restrict__ bytes, size_t nbytes, uint32_t stripe,
+                                          const uint64_t *__restrict__ stripe_base, uint32_t *__restrict__ accept_bits,
+                                          uint32_t *__restrict__ counts, uint32_t *__restrict__ slabs) {
     // T2 first: its entries hold 16-bit LDS addresses; the result window takes what T2 leaves of its region (16 KiB and
     // more for tables up to 30 KiB, 4 KiB at least).  The arrays are static, so P's base is a link-time constant.
     __shared__ __attribute__((aligned(16))) struct {
@@ -695,22 +740,36 @@ __global__ __launch_bounds__(kThreads) void match_stripes2_kernel(Dfa2Device pro
     const uint32_t stage_off = (uint32_t)((Dfa2::lds_bytes(prog) + 15) & ~(size_t)15);
     uint32_t *const stage = reinterpret_cast<uint32_t *>(lds.t2_and_stage + stage_off);
     const uint32_t stage_words = (kDfa2RegionBytes - stage_off) / 4;
-    for (uint32_t i = threadIdx.x; i < stage_words; i += kThreads) stage[i] = 0;
+    if (!ONEPASS)
+        for (uint32_t i = threadIdx.x; i < stage_words; i += kThreads) stage[i] = 0;
     __syncthreads();
 
     const size_t g0 = (size_t)blockIdx.x * kThreads;
-    const uint64_t window_word = line_of(stripe_base[g0]) >> 5;      // the workgroup's first stripe exists: uniform load
+    uint64_t window_word = 0;
+    if (!ONEPASS) window_word = line_of(stripe_base[g0]) >> 5;       // the workgroup's first stripe exists: uniform load
     const size_t g = g0 + threadIdx.x;
     const size_t start = g * (size_t)stripe;
     if (start < nbytes) {                                            // (no early return: the write-out below is collective)
     const size_t stripe_end = start + stripe;
     const size_t my_end = stripe_end < nbytes ? stripe_end : nbytes;
-    const uint64_t my_base = stripe_base[g];
-    const bool fresh = (my_base & kFreshStripe) != 0;
+    bool fresh = true;
+    typename std::conditional<ONEPASS, LocalResults, ResultsT<true>>::type res;
+    if constexpr (ONEPASS) {
+        res.begin(slabs + (size_t)blockIdx.x * slab_words_per_lane(stripe) * kThreads + threadIdx.x);
+    } else {
+        const uint64_t my_base = stripe_base[g];
+        fresh = (my_base & kFreshStripe) != 0;
+        res.begin_staged(line_of(my_base), window_word, !fresh, accept_bits, stage);
+        res.stage_words = stage_words;
+    }
     Dfa2::State st = fresh ? eng.fresh() : eng.skipping();
-    ResultsT<true> res;
-    res.begin_staged(line_of(my_base), window_word, !fresh, accept_bits, stage);
-    res.stage_words = stage_words;
+    auto clean = [](uint32_t w) -> uint32_t {                       // ONEPASS: bytes >= 0x80 -> 0x00
+        if (ONEPASS && __builtin_amdgcn_ballot_w64((w & 0x80808080u) != 0)) {
+            const uint32_t hi = (w & 0x80808080u) >> 7;             // 1 in every byte to clear
+            w &= ~(hi * 0xffu);
+        }
+        return w;
+    };
 
     size_t pos = start;
     const uint4 *src = reinterpret_cast<const uint4 *>(bytes + start);
@@ -724,10 +783,10 @@ __global__ __launch_bounds__(kThreads) void match_stripes2_kernel(Dfa2Device pro
     for (int r = 0; r < rounds; r++) {
 #pragma unroll
         for (int i = 0; i < kSlots; i++) {
-            eng.consume_dword(st, buf[i].x, res.bits);
-            eng.consume_dword(st, buf[i].y, res.bits);
-            eng.consume_dword(st, buf[i].z, res.bits);
-            eng.consume_dword(st, buf[i].w, res.bits);
+            eng.consume_dword(st, clean(buf[i].x), res.bits);
+            eng.consume_dword(st, clean(buf[i].y), res.bits);
+            eng.consume_dword(st, clean(buf[i].z), res.bits);
+            eng.consume_dword(st, clean(buf[i].w), res.bits);
             if (res.bits >> 15) res.flush();                 // <= 16 more results fit before the next check
         }
         if ((r & 3) == 3) res.flush();
@@ -737,6 +796,7 @@ __global__ __launch_bounds__(kThreads) void match_stripes2_kernel(Dfa2Device pro
         }
     }
     pos += (size_t)rounds * kRound;
+    auto byte_at = [&](size_t q) -> uint32_t { const uint32_t b = bytes[q]; return (ONEPASS && b >= 0x80u) ? 0u : b; };
 
     // ---- tail of the corpus inside my stripe (only the last stripe has one): whole pairs, then an odd last byte.
     // The odd byte is paired with a virtual '\n': if it is a '\n' itself the pair reports two line ends, of which
@@ -745,12 +805,12 @@ __global__ __launch_bounds__(kThreads) void match_stripes2_kernel(Dfa2Device pro
     bool closed_by_end_of_data = false;
     for (; pos + 2 <= my_end; pos += 2) {
         uint32_t lines, verdicts;
-        eng.step2(st, bytes[pos], bytes[pos + 1], lines, verdicts);
+        eng.step2(st, byte_at(pos), byte_at(pos + 1), lines, verdicts);
         res.bits = (res.bits << lines) | verdicts;
         if (res.bits >> 29) res.flush();
     }
     if (pos < my_end) {
-        const uint32_t b = bytes[pos];
+        const uint32_t b = byte_at(pos);
         uint32_t lines, verdicts;
         eng.step2(st, b, '\n', lines, verdicts);
         if (b == '\n') res.push(1, verdicts >> 1);
@@ -758,31 +818,78 @@ __global__ __launch_bounds__(kThreads) void match_stripes2_kernel(Dfa2Device pro
         pos++;
     }
     res.flush();
+    const uint32_t newlines = res.seen - (closed_by_end_of_data ? 1u : 0u);      // real '\n' inside my stripe
 
     // ---- follow my last line past the stripe end (same ownership rule as the byte kernel), pair by pair
+    if (ONEPASS && res.seen == 0) fresh = g == 0 || bytes[start - 1] == '\n';   // a stripe without any '\n': whose line is it?
     const bool started = fresh || res.seen > 0;
+    bool followed = false;
     if (!closed_by_end_of_data && started && bytes[my_end - 1] != '\n') {
         uint32_t lines = 0, verdicts = 0;
         while (pos + 16 <= nbytes && !lines) {
             const uint4 v = *reinterpret_cast<const uint4 *>(bytes + pos);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            const uint32_t w[4] = {clean(v.x), clean(v.y), clean(v.z), clean(v.w)};
 #pragma unroll
             for (int k = 0; k < 8; k++)
                 if (!lines) eng.step2(st, (w[k >> 1] >> (16 * (k & 1))) & 0xffu, (w[k >> 1] >> (16 * (k & 1) + 8)) & 0xffu, lines, verdicts);
             pos += 16;
         }
-        for (; pos + 2 <= nbytes && !lines; pos += 2) eng.step2(st, bytes[pos], bytes[pos + 1], lines, verdicts);
-        if (!lines) eng.step2(st, pos < nbytes ? bytes[pos] : '\n', '\n', lines, verdicts);   // end of data ends the line
+        for (; pos + 2 <= nbytes && !lines; pos += 2) eng.step2(st, byte_at(pos), byte_at(pos + 1), lines, verdicts);
+        if (!lines) eng.step2(st, pos < nbytes ? byte_at(pos) : '\n', '\n', lines, verdicts);   // end of data ends the line
         res.push(1, lines == 2 ? verdicts >> 1 : verdicts);     // only the first line end of the pair is mine
+        followed = true;
     }
     res.finish();
+    if (ONEPASS)
+        counts[g] = newlines | ((followed || closed_by_end_of_data) ? kExtraResult : 0u) | (bytes[my_end - 1] == '\n' ? kEndsOnNewline : 0u);
     }
-    // ---- write the window out: consecutive lanes, consecutive words (the atomics merge into whole lines in L2;
-    // the first and the last word of the window are shared with the neighbouring workgroups)
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < stage_words; i += kThreads) {
-        const uint32_t v = stage[i];
-        if (v) atomicOr(&accept_bits[window_word + i], v);
+    if (!ONEPASS) {
+        // ---- write the window out: consecutive lanes, consecutive words (the atomics merge into whole lines in L2;
+        // the first and the last word of the window are shared with the neighbouring workgroups)
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < stage_words; i += kThreads) {
+            const uint32_t v = stage[i];
+            if (v) atomicOr(&accept_bits[window_word + i], v);
+        }
+    }
+}
+__global__ __launch_bounds__(kThreads) void match_stripes2_kernel(Dfa2Device prog, const uint8_t *__restrict__ bytes, size_t nbytes,
+                                                                   uint32_t stripe, const uint64_t *__restrict__ stripe_base,
+                                                                   uint32_t *__restrict__ accept_bits) {
+    dfa2_body<false>(prog, bytes, nbytes, stripe, stripe_base, accept_bits, nullptr, nullptr);
+}
+__global__ __launch_bounds__(kThreads) void match_stripes2_onepass_kernel(Dfa2Device prog, const uint8_t *__restrict__ bytes, size_t nbytes,
+                                                                           uint32_t stripe, uint32_t *__restrict__ counts,
+                                                                           uint32_t *__restrict__ slabs) {
+    dfa2_body<true>(prog, bytes, nbytes, stripe, nullptr, nullptr, counts, slabs);
+}
+
+// One-pass mode, last step: lane = stripe.  The stream of stripe g (counts[g] results, the first of them dropped if the
+// stripe starts inside a line) goes to bits [base, base + n) of the accept bitmap, base = '\n' before the stripe.
+__global__ __launch_bounds__(256) void compact_streams_kernel(const uint32_t *__restrict__ counts, const uint64_t *__restrict__ stripe_base,
+                                                               size_t nstripes, uint32_t stripe, const uint32_t *__restrict__ slabs,
+                                                               uint32_t *__restrict__ accept_bits, size_t cap_words,
+                                                               uint32_t *__restrict__ overflow) {
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= nstripes) return;
+    const uint32_t c = counts[g];
+    const uint32_t n = (c & kCountMask) + ((c & kExtraResult) ? 1u : 0u);
+    if (!n) return;
+    const uint64_t b = stripe_base[g];
+    const uint64_t base = line_of(b);
+    const bool fresh = (b & kFreshStripe) != 0;
+    const uint32_t *src = slabs + (g / kThreads) * slab_words_per_lane(stripe) * kThreads + (g % kThreads);
+    for (uint32_t k = 0; k * 32 < n; k++) {
+        uint32_t v = src[(size_t)k * kThreads];
+        if (n - k * 32 < 32) v &= (1u << (n - k * 32)) - 1u;
+        if (k == 0 && !fresh) v &= ~1u;                          // that line belongs to the lane before me
+        if (!v) continue;
+        const uint64_t bit = base + (uint64_t)k * 32;
+        const uint64_t word = bit >> 5;
+        const uint32_t sh = (uint32_t)bit & 31u;
+        if (word + (sh ? 1 : 0) >= cap_words) { atomicOr(overflow, 1u); continue; }
+        atomicOr(&accept_bits[word], v << sh);
+        if (sh && (v >> (32u - sh))) atomicOr(&accept_bits[word + 1], v >> (32u - sh));
     }
 }
 
@@ -1169,7 +1276,7 @@ __global__ __launch_bounds__(256) void scan_chunk_sums_kernel(const uint32_t *__
     __shared__ uint64_t part[4];
     const size_t lo = (size_t)blockIdx.x * kScanChunk;
     uint64_t s = 0;
-    for (size_t i = lo + threadIdx.x; i < lo + kScanChunk && i < n; i += 256) s += counts[i] & ~kEndsOnNewline;
+    for (size_t i = lo + threadIdx.x; i < lo + kScanChunk && i < n; i += 256) s += counts[i] & kCountMask;
 #pragma unroll
     for (int d = 32; d; d >>= 1) s += __shfl_down(s, d, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
@@ -1198,7 +1305,7 @@ __global__ __launch_bounds__(256) void scan_chunks_kernel(const uint32_t *__rest
     __shared__ uint64_t sh[256];
     const size_t lo = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * (kScanChunk / 256);
     uint64_t s = 0;
-    for (size_t i = lo; i < lo + kScanChunk / 256 && i < n; i++) s += counts[i] & ~kEndsOnNewline;
+    for (size_t i = lo; i < lo + kScanChunk / 256 && i < n; i++) s += counts[i] & kCountMask;
     sh[threadIdx.x] = s;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1210,7 +1317,7 @@ __global__ __launch_bounds__(256) void scan_chunks_kernel(const uint32_t *__rest
     for (size_t i = lo; i < lo + kScanChunk / 256 && i < n; i++) {
         const bool fresh = i == 0 || (counts[i - 1] & kEndsOnNewline);
         base[i] = run | (fresh ? kFreshStripe : 0);
-        run += counts[i] & ~kEndsOnNewline;
+        run += counts[i] & kCountMask;
     }
 }
 
@@ -1556,6 +1663,24 @@ int match_stripes_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes,
     if (Dfa2::lds_bytes(p) > kDfa2MaxTable) return (int)hipErrorInvalidValue;
     size_t blocks = (nstripes + kThreads - 1) / kThreads;
     hipLaunchKernelGGL(match_stripes2_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept);
+    return (int)hipGetLastError();
+}
+size_t onepass_slab_words(size_t nstripes, uint32_t stripe) {
+    return ((nstripes + kThreads - 1) / kThreads) * slab_words_per_lane(stripe) * kThreads;
+}
+int match_onepass_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, size_t nstripes, uint32_t *counts,
+                       uint32_t *slabs, void *stream) {
+    if (!nstripes) return 0;
+    if (Dfa2::lds_bytes(p) > kDfa2MaxTable) return (int)hipErrorInvalidValue;
+    size_t blocks = (nstripes + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(match_stripes2_onepass_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, p, bytes, nbytes, stripe, counts, slabs);
+    return (int)hipGetLastError();
+}
+int compact_streams(const uint32_t *counts, const uint64_t *stripe_base, size_t nstripes, uint32_t stripe, const uint32_t *slabs,
+                    uint32_t *accept_bits, size_t cap_words, uint32_t *overflow, void *stream) {
+    if (!nstripes) return 0;
+    hipLaunchKernelGGL(compact_streams_kernel, dim3((unsigned)((nstripes + 255) / 256)), dim3(256), 0, (hipStream_t)stream, counts, stripe_base, nstripes,
+                       stripe, slabs, accept_bits, cap_words, overflow);
     return (int)hipGetLastError();
 }
 int match_extents_nfa(const NfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim, uint8_t *accept,

@@ -439,6 +439,58 @@ def test_wave_cooperative_engine_on_large_automata():
         assert (r.get_acceptance_iter(t).advance().value() is not None) == o.accepts(t)
 
 
+def _bits_to_bytes(words, n):
+    w = words.cpu().numpy().view(np.uint32)
+    return ((w[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).astype(np.uint8).reshape(-1)[:n]
+
+
+def test_one_shot_entry_reads_the_text_once_and_agrees_with_the_indexed_path():
+    """rrx_match_device: no rrx_corpus, the newline index is a by-product of the match (stride-2 table engine) - against
+    the oracle and against the indexed path: ragged lines, empty lines, lines longer than a stripe, bytes >= 0x80 and 0x00
+    (the one-pass kernel cannot rely on an index pass to route such corpora elsewhere), with and without a final '\n',
+    sizes around stripe and workgroup multiples; an engine without a stride-2 table takes the two-pass fallback."""
+    rng = np.random.default_rng(51)
+    p = "(a|b)*abb(a|b)*"
+    o = OracleRegex(p)
+    alphabet = np.frombuffer(b"ab\n", dtype=np.uint8)
+    sizes = [1, 2, 15, 16, 17, 127, 128, 129, 2047, 2048, 2049, 4096 + 5, 1024 * 2048, 1024 * 2048 + 2048 + 77, 5_000_003]
+    for n in sizes:
+        for variant in ("plain", "dirty", "long"):
+            probs = [0.47, 0.47, 0.06] if variant != "long" else [0.4999, 0.4999, 0.0002]
+            data = alphabet[rng.choice(3, size=n, p=probs)].copy()
+            if variant == "dirty" and n > 8:
+                idx = rng.integers(0, n, size=max(1, n // 500))
+                data[idx] = rng.choice(np.array([0x00, 0x80, 0xff, 0xc3], dtype=np.uint8), size=len(idx))
+            for last in (10, 97):
+                data[-1] = last
+                want = o.match_lines(data)
+                dev = torch.from_numpy(data.copy()).cuda()
+                for e in (rr.ENGINE_AUTO, rr.ENGINE_NFA):
+                    r = rr.RRegex(p, e)
+                    bits, nlines = r.match_device_bits(dev)
+                    assert nlines == len(want), (n, variant, last, r.engine_name)
+                    got = _bits_to_bytes(bits, nlines)
+                    bad = np.nonzero(got != want)[0]
+                    assert bad.size == 0, (n, variant, last, r.engine_name, "first bad line", int(bad[0]))
+                if n > 100000:
+                    break
+    # a bitmap that is too small is reported, not overrun
+    data = np.frombuffer(b"a\n" * 5000, dtype=np.uint8).copy()
+    with pytest.raises(rr.RRegexError, match="too small"):
+        rr.RRegex("a").match_device_bits(torch.from_numpy(data).cuda(), cap_lines=1024)
+    # BASELINE corpora, one-shot == indexed path
+    import synth
+    for kind, pattern, nbytes in (("url", U2, 64 << 20), ("kwlines", K1000, 16 << 20), ("arepeat", "a{1,300}", 16 << 20)):
+        host = synth.corpus(kind, 13, nbytes)
+        dev = torch.from_numpy(host).cuda()
+        r = rr.RRegex(pattern)
+        assert r.engine_name == "dfa-stride2-table"
+        bits, nlines = r.match_device_bits(dev)
+        corpus = rr.Corpus(dev)
+        assert nlines == corpus.num_lines
+        assert torch.equal(bits, r.match_corpus_bits(corpus)), kind
+
+
 def test_block_cooperative_engine_beyond_4096_positions():
     """An automaton with more than 4096 positions (5003: no table form exists, beyond the group engine) compiles to the
     block-cooperative engine and matches the oracle: batch kernel, extents kernel, iterator facade."""
