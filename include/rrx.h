@@ -79,9 +79,9 @@ size_t rrx_corpus_bitmap_words(const rrx_corpus *c);   /* 32-bit words of the ac
  * (i.e. *it has a value, regex.h:160-162; its Match is then [start of string i, its terminator)).
  * d_accept_bits holds rrx_corpus_bitmap_words() words; it is zeroed and filled on `stream`.                  */
 int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accept_bits, void *stream);
-/* The same for a device-resident buffer that has no rrx_corpus yet, in ONE call: with the stride-2 table engine the
+/* The same for a device-resident buffer that has no rrx_corpus yet, in ONE call: with the lane engines (tables, NFA) the
  * text is read once (the newline index is a by-product of the match: per-stripe counts, a scan, a compaction of the
- * lanes' verdict streams); other engines build the index first.  d_accept_bits holds cap_words words (zeroed and
+ * lanes' verdict streams); the cooperative engines build the index first.  d_accept_bits holds cap_words words (zeroed and
  * filled on `stream`); *nlines = number of strings; RRX_ERR_ARG if the bitmap is too small.  Synchronous.           */
 int rrx_match_device(const rrx_regex *re, int device, const void *d_bytes, size_t nbytes, uint32_t *d_accept_bits,
                      size_t cap_words, size_t *nlines, void *stream);

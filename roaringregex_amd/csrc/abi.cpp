@@ -550,10 +550,10 @@ int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accep
     return RRX_OK;
 }
 
-// One-shot entry: a device-resident buffer that nobody has indexed.  With the stride-2 table engine the text is read ONCE:
-// the match kernel counts the '\n' of every stripe on the side and leaves every lane's verdicts as a stream of its own;
-// a scan of the counts and a small compaction kernel then put the streams at their line numbers.  Other engines build
-// the index first (two passes).  Synchronous: *nlines is read back.
+// One-shot entry: a device-resident buffer that nobody has indexed.  With the lane engines (tables and NFA) the text is
+// read ONCE: the match kernel counts the '\n' of every stripe on the side and leaves every lane's verdicts as a stream of
+// its own; a scan of the counts and a small compaction kernel then put the streams at their line numbers.  The
+// cooperative engines build the index first (two passes).  Synchronous: *nlines is read back.
 int rrx_match_device(const rrx_regex *re, int device, const void *d_bytes, size_t nbytes, uint32_t *d_accept_bits, size_t cap_words,
                      size_t *nlines, void *stream) {
     if (!re || (nbytes && !d_bytes) || !nlines || (cap_words && !d_accept_bits)) return fail(RRX_ERR_ARG, "null argument");
@@ -562,7 +562,7 @@ int rrx_match_device(const rrx_regex *re, int device, const void *d_bytes, size_
     HIP_TRY(hipSetDevice(device));
     if (!nbytes) return RRX_OK;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (!(re->engine == RRX_ENGINE_DFA && re->has_dfa2)) {                 // two passes: index, then match
+    if (re->engine != RRX_ENGINE_DFA && re->engine != RRX_ENGINE_NFA) {     // cooperative engines: two passes (index, then match)
         rrx_corpus *c = nullptr;
         int rc = rrx_corpus_create(device, d_bytes, nbytes, stream, &c);
         if (rc) return rc;
@@ -593,7 +593,9 @@ int rrx_match_device(const rrx_regex *re, int device, const void *d_bytes, size_
     uint32_t *d_slabs = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(buf) + counts_bytes + base_bytes);
     HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(uint32_t), st));
     if (cap_words) HIP_TRY(hipMemsetAsync(d_accept_bits, 0, cap_words * sizeof(uint32_t), st));
-    int e = dev::match_onepass_dfa2(t->dfa2, bytes, nbytes, stripe, nstripes, d_counts, d_slabs, stream);
+    int e = re->engine == RRX_ENGINE_NFA ? dev::match_onepass_nfa(t->nfa, bytes, nbytes, stripe, nstripes, d_counts, d_slabs, stream)
+            : re->has_dfa2               ? dev::match_onepass_dfa2(t->dfa2, bytes, nbytes, stripe, nstripes, d_counts, d_slabs, stream)
+                                         : dev::match_onepass_dfa(t->line, bytes, nbytes, stripe, nstripes, d_counts, d_slabs, stream);
     if (!e) e = dev::scan_counts(d_counts, d_base, d_base + nstripes + 1, nstripes, stream);
     if (!e) e = dev::compact_streams(d_counts, d_base, nstripes, stripe, d_slabs, d_accept_bits, cap_words, d_flag, stream);
     if (e) return hip_fail((hipError_t)e, "one-pass launch");

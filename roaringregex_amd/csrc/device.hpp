@@ -125,6 +125,10 @@ int match_stripes_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes,
 size_t onepass_slab_words(size_t nstripes, uint32_t stripe);
 int match_onepass_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, size_t nstripes, uint32_t *counts,
                        uint32_t *slabs, void *stream);
+int match_onepass_dfa(const LineDfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, size_t nstripes, uint32_t *counts,
+                      uint32_t *slabs, void *stream);
+int match_onepass_nfa(const NfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, size_t nstripes, uint32_t *counts,
+                      uint32_t *slabs, void *stream);
 int compact_streams(const uint32_t *counts, const uint64_t *stripe_base, size_t nstripes, uint32_t stripe, const uint32_t *slabs,
                     uint32_t *accept_bits, size_t cap_words, uint32_t *overflow, void *stream);
 

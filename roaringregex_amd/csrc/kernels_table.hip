@@ -1,0 +1,849 @@
+// kernels_table.hip — table engines (byte-stride and stride-2), the line index, the stream compaction of the one-shot
+// entry, search and the one-long-string kernels.  Shared device code: kernels_common.hpp.
+#include "kernels_common.hpp"
+
+namespace rrx {
+namespace dev {
+namespace {
+
+// ============================================================================================ engines
+// Line-mode engines expose
+//     void load(program, lds)               cooperative table copy into LDS
+//     State fresh() / State skipping()      start of a line / inside a line owned by somebody else
+//     void step(State&, c, nl, acc)         consume one byte; nl = 1 iff it was '\n', acc = verdict of the
+//                                           line it ended (valid when nl)
+
+// ---- wide / classed table DFA: '\n' handling folded into the table -------------------------------
+template <bool WIDE, bool CLAMP>
+struct LineDfaEngine {
+    static constexpr bool kStaged = true;      // results go through the workgroup's LDS window (ResultsT<true>)
+    static constexpr bool kEightWaves = false;
+    static constexpr int kRoundBytes = kRound;
+    // Table entry: bits 0..15 = byte offset of the next row, byte 2 = 1 iff the consumed byte was '\n',
+    // byte 3 = verdict of the line it ended.  (16-bit entries read with ds_read_u16 measured 3-4 % slower.)
+    struct State { uint32_t e; };
+    const uint8_t *tab;                    // LDS, byte-addressed
+    const uint8_t *cls;                    // LDS [256] (classed form)
+    uint32_t start_off, dead_off;
+    uint32_t col_shift;                    // log2(bytes between neighbouring columns) = 2 + log2(copies)
+
+    static size_t lds_bytes(const LineDfaDevice &p) { return (size_t)p.nrows * p.stride * 4 + (WIDE ? 0 : 256); }
+    typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
+    __device__ void load(const LineDfaDevice &p, uint8_t *lds) {
+        uint32_t *t = reinterpret_cast<uint32_t *>(lds);
+        const int n = (int)(p.nrows * p.stride);
+        // In the SDWA form the low half of an entry is the ABSOLUTE LDS address of the next row, so that
+        // e.word[0] + 4*c is the address to read, with no base to add per byte.
+        const uint32_t base = (WIDE && !CLAMP) ? (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds : 0u;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) t[i] = p.table[i] + base;
+        if (!WIDE) {
+            uint8_t *c = lds + (size_t)n * 4;
+            for (int i = threadIdx.x; i < 256; i += blockDim.x) c[i] = p.cls[i];
+            cls = c;
+        }
+        tab = lds;
+        // R interleaved copies (wide form): lane l lives in copy l % R, whose dwords sit in banks = l (mod R)
+        const uint32_t copy = WIDE ? (threadIdx.x & ((1u << p.rep_log2) - 1u)) * 4u : 0u;
+        col_shift = 2u + (WIDE ? p.rep_log2 : 0u);
+        start_off = p.start_off + base + copy;
+        dead_off = base + copy;
+    }
+    __device__ __forceinline__ State fresh() const { return State{start_off}; }
+    __device__ __forceinline__ State skipping() const { return State{dead_off}; }   // dead row: waits for '\n'
+    // Byte K of text word w, fused with the result accumulation bits = (bits << nl) | acc.  A wave64 integer
+    // VALU op costs 4 cycles on a CDNA4 SIMD, so the step is written as 4 VALU + 1 LDS per byte with the
+    // field extractions folded into SDWA operand selects (hipcc emits 6-7 for the plain C form below):
+    //     c4   = w.byte[K] << 2                 v_lshlrev_b32_sdwa   src1_sel:BYTE_K
+    //     addr = e.word[0] + c4                 v_add_u32_sdwa       src0_sel:WORD_0
+    //     e    = LDS[addr]                      ds_read_b32
+    //     bits = bits << e.byte[2]              v_lshlrev_b32_sdwa   src0_sel:BYTE_2
+    //     bits = bits |  e.byte[3]              v_or_b32_sdwa        src0_sel:BYTE_3
+    template <int K>
+    __device__ __forceinline__ void consume(State &st, uint32_t w, uint32_t &bits) const {
+        if constexpr (WIDE && !CLAMP) {
+            // One asm block per byte (separate statements made hipcc pad every byte with an s_nop).  The block
+            // waits for its own LDS read; the only other memory traffic of the wave are global loads (vmcnt).
+            uint32_t t0, t1;
+#define RRX_STEP(SEL)                                                                                                        \
+            asm volatile("v_lshlrev_b32_sdwa %[c4], %[two], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL "\n\t" \
+                         "v_add_u32_sdwa %[ad], %[e], %[c4] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"       \
+                         "ds_read_b32 %[e], %[ad]\n\t"                                                                                  \
+                         "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
+                         "v_lshlrev_b32_sdwa %[b], %[e], %[b] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n\t"     \
+                         "v_or_b32_sdwa %[b], %[e], %[b] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD"              \
+                         : [e] "+v"(st.e), [b] "+v"(bits), [c4] "=&v"(t0), [ad] "=&v"(t1)                                               \
+                         : [w] "v"(w), [two] "v"(col_shift)                                                                             \
+                         : "memory")
+            if constexpr (K == 0) RRX_STEP("BYTE_0");
+            if constexpr (K == 1) RRX_STEP("BYTE_1");
+            if constexpr (K == 2) RRX_STEP("BYTE_2");
+            if constexpr (K == 3) RRX_STEP("BYTE_3");
+#undef RRX_STEP
+        } else {
+            uint32_t nl, acc;
+            step(st, (w >> (8 * K)) & 0xffu, nl, acc);
+            bits = (bits << nl) | acc;
+        }
+    }
+    __device__ __forceinline__ void consume_word(State &st, uint32_t w, uint32_t &bits) const {
+        consume<0>(st, w, bits); consume<1>(st, w, bits); consume<2>(st, w, bits); consume<3>(st, w, bits);
+    }
+    __device__ __forceinline__ void step(State &st, uint32_t c, uint32_t &nl, uint32_t &acc) const {
+        uint32_t col;
+        if (WIDE) col = CLAMP ? (c < 128u ? c : 128u) : c;      // !CLAMP: the corpus holds no byte >= 0x80
+        else col = cls[c];
+        const uint32_t off = (st.e & 0xffffu) + (col << col_shift);      // (absolute LDS address in the SDWA form)
+        st.e = (WIDE && !CLAMP) ? *reinterpret_cast<lds_u32_ptr>(off) : *reinterpret_cast<const uint32_t *>(tab + off);
+        nl = (st.e >> 16) & 0xffu;
+        acc = st.e >> 24;
+    }
+};
+
+// ---- table DFA whose table stays in global memory (L2-resident): any automaton up to 65535 interned sets ----
+struct LineDfaGlobalEngine {
+    static constexpr bool kStaged = true;
+    static constexpr bool kEightWaves = false;
+    static constexpr int kRoundBytes = kRound;
+    struct State { uint32_t e; };          // low 24 bits = index of the current row's first entry
+    const uint32_t *__restrict__ tab;      // HBM / L2
+    const uint8_t *cls;                    // LDS [256]
+    uint32_t start_off;
+
+    static size_t lds_bytes(const LineDfaDevice &) { return 256; }
+    __device__ void load(const LineDfaDevice &p, uint8_t *lds) {
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) lds[i] = p.cls[i];
+        cls = lds; tab = p.table; start_off = p.start_off;
+    }
+    __device__ __forceinline__ State fresh() const { return State{start_off}; }
+    __device__ __forceinline__ State skipping() const { return State{0}; }
+    __device__ __forceinline__ void step(State &st, uint32_t c, uint32_t &nl, uint32_t &acc) const {
+        st.e = tab[(st.e & 0xffffffu) + cls[c]];
+        nl = (st.e >> 30) & 1u;
+        acc = st.e >> 31;
+    }
+    template <int K>
+    __device__ __forceinline__ void consume(State &st, uint32_t w, uint32_t &bits) const {
+        uint32_t nl, acc;
+        step(st, (w >> (8 * K)) & 0xffu, nl, acc);
+        bits = (bits << nl) | acc;
+    }
+    __device__ __forceinline__ void consume_word(State &st, uint32_t w, uint32_t &bits) const {
+        consume<0>(st, w, bits); consume<1>(st, w, bits); consume<2>(st, w, bits); consume<3>(st, w, bits);
+    }
+};
+
+struct PlainDfaEngine {
+    struct State { uint32_t s; };
+    const uint8_t *cls;     // LDS [256]
+    const uint16_t *next;   // LDS [nstates][ncls]
+    const uint8_t *acc;     // LDS [nstates]
+    uint32_t ncls, start;
+
+    static size_t lds_bytes(const DfaDevice &p) {
+        size_t t = ((size_t)p.nstates * p.ncls * 2 + 15) & ~(size_t)15;
+        return t + 256 + ((p.nstates + 15) & ~15u);
+    }
+    __device__ void load(const DfaDevice &p, uint8_t *lds) {
+        size_t tb = ((size_t)p.nstates * p.ncls * 2 + 15) & ~(size_t)15;
+        uint16_t *n = reinterpret_cast<uint16_t *>(lds);
+        uint8_t *c = lds + tb;
+        uint8_t *a = c + 256;
+        for (int i = threadIdx.x; i < (int)(p.nstates * p.ncls); i += blockDim.x) n[i] = p.next[i];
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) c[i] = p.cls[i];
+        for (int i = threadIdx.x; i < (int)p.nstates; i += blockDim.x) a[i] = p.acc[i];
+        next = n; cls = c; acc = a; ncls = p.ncls; start = p.start;
+    }
+    __device__ __forceinline__ void reset(State &st) const { st.s = start; }
+    __device__ __forceinline__ void kill(State &st) const { st.s = 0; }
+    __device__ __forceinline__ bool accepting(const State &st) const { return acc[st.s] != 0; }
+    __device__ __forceinline__ void step(State &st, uint32_t c) const { st.s = next[st.s * ncls + cls[c]]; }
+};
+
+// The same automaton with its table left in HBM/L2 (tables beyond the LDS budget: the batch kernel's "global" form,
+// here for explicit items and single strings).  One dependent L2 read per byte.
+struct PlainDfaGlobalEngine {
+    struct State { uint32_t s; };
+    const uint8_t *cls;                   // LDS [256]
+    const uint16_t *__restrict__ next;    // HBM / L2 [nstates][ncls]
+    const uint8_t *__restrict__ acc;      // HBM / L2 [nstates]
+    uint32_t ncls, start;
+
+    static size_t lds_bytes(const DfaDevice &) { return 256; }
+    __device__ void load(const DfaDevice &p, uint8_t *lds) {
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) lds[i] = p.cls[i];
+        cls = lds; next = p.next; acc = p.acc; ncls = p.ncls; start = p.start;
+    }
+    __device__ __forceinline__ void reset(State &st) const { st.s = start; }
+    __device__ __forceinline__ void kill(State &st) const { st.s = 0; }
+    __device__ __forceinline__ bool accepting(const State &st) const { return acc[st.s] != 0; }
+    __device__ __forceinline__ void step(State &st, uint32_t c) const { st.s = next[(size_t)st.s * ncls + cls[c]]; }
+};
+
+// ============================================================================================ stride-2 table kernel
+// The per-byte table step is bounded by the latency of its dependent LDS round trip (add -> ds_read -> wait, ~210
+// cycles at 8 chains per SIMD).  Here ONE dependent lookup consumes TWO bytes: the pair's column comes from the
+// state-independent table P (its read does not wait for the state), then e = T2[row(e)][column].  U2: 46 distinct
+// pair columns of 289 class pairs, T2 = 16 KiB.  Per pair: 6 VALU + 2 LDS reads (3 VALU per byte).
+struct Dfa2 {
+    typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
+    struct State { uint32_t e; };          // low 16 bits = LDS address of the current row (of this lane's copy)
+    const uint16_t *P;                     // LDS (a static array at a link-time address: no base to add per pair)
+    uint32_t start_off, dead_off;
+
+    __host__ __device__ static size_t lds_bytes(const Dfa2Device &p) { return (size_t)p.nrows * p.stride * 4; }     // dynamic part: T2
+    __device__ void load(const Dfa2Device &p, uint16_t *p_lds, uint8_t *t_lds) {
+        uint32_t *pl = reinterpret_cast<uint32_t *>(p_lds);
+        const uint32_t *ps = reinterpret_cast<const uint32_t *>(p.P);
+        for (int i = threadIdx.x; i < (int)(kDfa2PBytes / 4); i += blockDim.x) pl[i] = ps[i];
+        uint32_t *t = reinterpret_cast<uint32_t *>(t_lds);
+        const uint32_t tbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)t_lds;
+        const int n = (int)(p.nrows * p.stride);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) t[i] = p.T2[i] + tbase;
+        const uint32_t copy = (threadIdx.x & ((1u << p.rep_log2) - 1u)) * 4u;
+        P = p_lds;
+        start_off = p.start_off + tbase + copy;
+        dead_off = tbase + copy;
+    }
+    __device__ __forceinline__ State fresh() const { return State{start_off}; }
+    __device__ __forceinline__ State skipping() const { return State{dead_off}; }
+    // generic pair step (tails and the walk past the stripe end)
+    __device__ __forceinline__ void step2(State &st, uint32_t c1, uint32_t c2, uint32_t &lines, uint32_t &verdicts) const {
+        const uint32_t col = P[c1 * kDfa2PStride + c2];
+        st.e = *reinterpret_cast<lds_u32_ptr>((st.e & 0xffffu) + col);
+        lines = (st.e >> 16) & 0xffu;
+        verdicts = st.e >> 24;
+    }
+    // the four bytes of text word w (two pairs), fused with bits = (bits << lines) | verdicts.  Per pair:
+    //     t    = (2 c1) * 130                v_mul_u32_u24_sdwa   src0_sel:BYTE_even
+    //     idx  = t + 2 c2                    v_add_u32_sdwa       src1_sel:BYTE_odd        (byte offset into P)
+    //     col  = P[idx]                      ds_read_u16                                   (does not wait for the state)
+    //     addr = e.word[0] + col             v_add_u32_sdwa       src0_sel:WORD_0
+    //     e    = LDS[addr]                   ds_read_b32
+    //     bits = (bits << e.byte[2]) | e.byte[3]                 2 x SDWA
+    __device__ __forceinline__ void consume_dword(State &st, uint32_t w, uint32_t &bits) const {
+        const uint32_t w2 = w << 1;                      // every byte < 0x80: doubling stays inside the byte
+        const uint32_t stride = kDfa2PStride;
+        uint32_t ta, ia, tb, ib;
+        asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(ta) : "v"(w2), "v"(stride));
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(ia) : "v"(ta), "v"(w2));
+        asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(tb) : "v"(w2), "v"(stride));
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(ib) : "v"(tb), "v"(w2));
+#define RRX_LDS_U16(x) (*reinterpret_cast<const uint16_t *>(reinterpret_cast<const uint8_t *>(P) + (x)))
+#define RRX_LDS_U32(x) (*reinterpret_cast<lds_u32_ptr>(x))
+        const uint32_t ca = RRX_LDS_U16(ia);
+        const uint32_t cb = RRX_LDS_U16(ib);
+        uint32_t addr;
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(addr) : "v"(st.e), "v"(ca));
+        st.e = RRX_LDS_U32(addr);
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(bits) : "v"(st.e), "v"(bits));
+        asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(bits) : "v"(st.e), "v"(bits));
+        asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(addr) : "v"(st.e), "v"(cb));
+        st.e = RRX_LDS_U32(addr);
+        asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(bits) : "v"(st.e), "v"(bits));
+        asm("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(bits) : "v"(st.e), "v"(bits));
+    }
+};
+
+// Same stripe geometry, feed and result path as match_stripes_kernel; pairs are aligned to even byte positions
+// (stripes are even-sized), a line end may fall on either byte of a pair.
+// ONEPASS (rrx_match_device): no line index yet.  Every lane starts in the start state (a lane that begins inside a line
+// produces a verdict for the fragment, which the compaction drops), counts its '\n' on the side, and keeps its verdict
+// stream in the workgroup's slab (LocalResults).  Bytes >= 0x80 cannot index the pair table: a text word that holds one is
+// rewritten with 0x00 in their place (which rejects the line just the same) under a wave-uniform branch.
+template <bool ONEPASS>
+__device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t *__restrict__ bytes, size_t nbytes, uint32_t stripe,
+                                          const uint64_t *__restrict__ stripe_base, uint32_t *__restrict__ accept_bits,
+                                          uint32_t *__restrict__ counts, uint32_t *__restrict__ slabs) {
+    // T2 first: its entries hold 16-bit LDS addresses; the result window takes what T2 leaves of its region (16 KiB and
+    // more for tables up to 30 KiB, 4 KiB at least).  The arrays are static, so P's base is a link-time constant.
+    __shared__ __attribute__((aligned(16))) struct {
+        uint8_t t2_and_stage[kDfa2RegionBytes];
+        uint16_t p[kDfa2PBytes / 2];
+    } lds;
+    Dfa2 eng;
+    eng.load(prog, lds.p, lds.t2_and_stage);
+    const uint32_t stage_off = (uint32_t)((Dfa2::lds_bytes(prog) + 15) & ~(size_t)15);
+    uint32_t *const stage = reinterpret_cast<uint32_t *>(lds.t2_and_stage + stage_off);
+    const uint32_t stage_words = (kDfa2RegionBytes - stage_off) / 4;
+    if (!ONEPASS)
+        for (uint32_t i = threadIdx.x; i < stage_words; i += kThreads) stage[i] = 0;
+    __syncthreads();
+
+    const size_t g0 = (size_t)blockIdx.x * kThreads;
+    uint64_t window_word = 0;
+    if (!ONEPASS) window_word = line_of(stripe_base[g0]) >> 5;       // the workgroup's first stripe exists: uniform load
+    const size_t g = g0 + threadIdx.x;
+    const size_t start = g * (size_t)stripe;
+    if (start < nbytes) {                                            // (no early return: the write-out below is collective)
+    const size_t stripe_end = start + stripe;
+    const size_t my_end = stripe_end < nbytes ? stripe_end : nbytes;
+    bool fresh = true;
+    typename std::conditional<ONEPASS, LocalResults, ResultsT<true>>::type res;
+    if constexpr (ONEPASS) {
+        res.begin(slabs + (size_t)blockIdx.x * slab_words_per_lane(stripe) * kThreads + threadIdx.x);
+    } else {
+        const uint64_t my_base = stripe_base[g];
+        fresh = (my_base & kFreshStripe) != 0;
+        res.begin_staged(line_of(my_base), window_word, !fresh, accept_bits, stage);
+        res.stage_words = stage_words;
+    }
+    Dfa2::State st = fresh ? eng.fresh() : eng.skipping();
+    auto clean = [](uint32_t w) -> uint32_t {                       // ONEPASS: bytes >= 0x80 -> 0x00
+        if (ONEPASS && __builtin_amdgcn_ballot_w64((w & 0x80808080u) != 0)) {
+            const uint32_t hi = (w & 0x80808080u) >> 7;             // 1 in every byte to clear
+            w &= ~(hi * 0xffu);
+        }
+        return w;
+    };
+
+    size_t pos = start;
+    const uint4 *src = reinterpret_cast<const uint4 *>(bytes + start);
+    constexpr int kSlots = kRound / 16;
+    const int rounds = (int)((my_end - start) / kRound);
+    uint4 buf[kSlots];
+    if (rounds > 0) {
+#pragma unroll
+        for (int i = 0; i < kSlots; i++) buf[i] = load_text(src + i);
+    }
+    for (int r = 0; r < rounds; r++) {
+#pragma unroll
+        for (int i = 0; i < kSlots; i++) {
+            eng.consume_dword(st, clean(buf[i].x), res.bits);
+            eng.consume_dword(st, clean(buf[i].y), res.bits);
+            eng.consume_dword(st, clean(buf[i].z), res.bits);
+            eng.consume_dword(st, clean(buf[i].w), res.bits);
+            if (res.bits >> 15) res.flush();                 // <= 16 more results fit before the next check
+        }
+        if ((r & 3) == 3) res.flush();
+        if (r + 1 < rounds) {
+#pragma unroll
+            for (int i = 0; i < kSlots; i++) buf[i] = load_text(src + (r + 1) * kSlots + i);
+        }
+    }
+    pos += (size_t)rounds * kRound;
+    auto byte_at = [&](size_t q) -> uint32_t { const uint32_t b = bytes[q]; return (ONEPASS && b >= 0x80u) ? 0u : b; };
+
+    // ---- tail of the corpus inside my stripe (only the last stripe has one): whole pairs, then an odd last byte.
+    // The odd byte is paired with a virtual '\n': if it is a '\n' itself the pair reports two line ends, of which
+    // only the first exists; otherwise the virtual '\n' is the end of data ending the last line, and the walk
+    // below must not end it again.
+    bool closed_by_end_of_data = false;
+    for (; pos + 2 <= my_end; pos += 2) {
+        uint32_t lines, verdicts;
+        eng.step2(st, byte_at(pos), byte_at(pos + 1), lines, verdicts);
+        res.bits = (res.bits << lines) | verdicts;
+        if (res.bits >> 29) res.flush();
+    }
+    if (pos < my_end) {
+        const uint32_t b = byte_at(pos);
+        uint32_t lines, verdicts;
+        eng.step2(st, b, '\n', lines, verdicts);
+        if (b == '\n') res.push(1, verdicts >> 1);
+        else { res.push(1, verdicts); closed_by_end_of_data = true; }
+        pos++;
+    }
+    res.flush();
+    const uint32_t newlines = res.seen - (closed_by_end_of_data ? 1u : 0u);      // real '\n' inside my stripe
+
+    // ---- follow my last line past the stripe end (same ownership rule as the byte kernel), pair by pair
+    if (ONEPASS && res.seen == 0) fresh = g == 0 || bytes[start - 1] == '\n';   // a stripe without any '\n': whose line is it?
+    const bool started = fresh || res.seen > 0;
+    bool followed = false;
+    if (!closed_by_end_of_data && started && bytes[my_end - 1] != '\n') {
+        uint32_t lines = 0, verdicts = 0;
+        while (pos + 16 <= nbytes && !lines) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(bytes + pos);
+            const uint32_t w[4] = {clean(v.x), clean(v.y), clean(v.z), clean(v.w)};
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (!lines) eng.step2(st, (w[k >> 1] >> (16 * (k & 1))) & 0xffu, (w[k >> 1] >> (16 * (k & 1) + 8)) & 0xffu, lines, verdicts);
+            pos += 16;
+        }
+        for (; pos + 2 <= nbytes && !lines; pos += 2) eng.step2(st, byte_at(pos), byte_at(pos + 1), lines, verdicts);
+        if (!lines) eng.step2(st, pos < nbytes ? byte_at(pos) : '\n', '\n', lines, verdicts);   // end of data ends the line
+        res.push(1, lines == 2 ? verdicts >> 1 : verdicts);     // only the first line end of the pair is mine
+        followed = true;
+    }
+    res.finish();
+    if (ONEPASS)
+        counts[g] = newlines | ((followed || closed_by_end_of_data) ? kExtraResult : 0u) | (bytes[my_end - 1] == '\n' ? kEndsOnNewline : 0u);
+    }
+    if (!ONEPASS) {
+        // ---- write the window out: consecutive lanes, consecutive words (the atomics merge into whole lines in L2;
+        // the first and the last word of the window are shared with the neighbouring workgroups)
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < stage_words; i += kThreads) {
+            const uint32_t v = stage[i];
+            if (v) atomicOr(&accept_bits[window_word + i], v);
+        }
+    }
+}
+__global__ __launch_bounds__(kThreads) void match_stripes2_kernel(Dfa2Device prog, const uint8_t *__restrict__ bytes, size_t nbytes,
+                                                                   uint32_t stripe, const uint64_t *__restrict__ stripe_base,
+                                                                   uint32_t *__restrict__ accept_bits) {
+    dfa2_body<false>(prog, bytes, nbytes, stripe, stripe_base, accept_bits, nullptr, nullptr);
+}
+__global__ __launch_bounds__(kThreads) void match_stripes2_onepass_kernel(Dfa2Device prog, const uint8_t *__restrict__ bytes, size_t nbytes,
+                                                                           uint32_t stripe, uint32_t *__restrict__ counts,
+                                                                           uint32_t *__restrict__ slabs) {
+    dfa2_body<true>(prog, bytes, nbytes, stripe, nullptr, nullptr, counts, slabs);
+}
+
+// One-pass mode, last step: lane = stripe.  The stream of stripe g (counts[g] results, the first of them dropped if the
+// stripe starts inside a line) goes to bits [base, base + n) of the accept bitmap, base = '\n' before the stripe.
+__global__ __launch_bounds__(256) void compact_streams_kernel(const uint32_t *__restrict__ counts, const uint64_t *__restrict__ stripe_base,
+                                                               size_t nstripes, uint32_t stripe, const uint32_t *__restrict__ slabs,
+                                                               uint32_t *__restrict__ accept_bits, size_t cap_words,
+                                                               uint32_t *__restrict__ overflow) {
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= nstripes) return;
+    const uint32_t c = counts[g];
+    const uint32_t n = (c & kCountMask) + ((c & kExtraResult) ? 1u : 0u);
+    if (!n) return;
+    const uint64_t b = stripe_base[g];
+    const uint64_t base = line_of(b);
+    const bool fresh = (b & kFreshStripe) != 0;
+    const uint32_t *src = slabs + (g / kThreads) * slab_words_per_lane(stripe) * kThreads + (g % kThreads);
+    for (uint32_t k = 0; k * 32 < n; k++) {
+        uint32_t v = src[(size_t)k * kThreads];
+        if (n - k * 32 < 32) v &= (1u << (n - k * 32)) - 1u;
+        if (k == 0 && !fresh) v &= ~1u;                          // that line belongs to the lane before me
+        if (!v) continue;
+        const uint64_t bit = base + (uint64_t)k * 32;
+        const uint64_t word = bit >> 5;
+        const uint32_t sh = (uint32_t)bit & 31u;
+        if (word + (sh ? 1 : 0) >= cap_words) { atomicOr(overflow, 1u); continue; }
+        atomicOr(&accept_bits[word], v << sh);
+        if (sh && (v >> (32u - sh))) atomicOr(&accept_bits[word + 1], v >> (32u - sh));
+    }
+}
+
+// ============================================================================================ line index
+// counts[g] = number of '\n' in stripe g, streamed exactly like the match kernel streams it.  Also raises
+// *flags bit 0 if any byte >= 0x80 occurs (the match kernel then clamps such bytes to the dead column).
+__global__ __launch_bounds__(256) void count_newlines_kernel(const uint8_t *__restrict__ bytes, size_t nbytes, uint32_t stripe,
+                                                              uint32_t *__restrict__ counts, size_t nstripes,
+                                                              uint32_t *__restrict__ flags) {
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (g >= nstripes) return;
+    const size_t start = g * (size_t)stripe;
+    const size_t end = start + stripe < nbytes ? start + stripe : nbytes;
+    const uint4 *src = reinterpret_cast<const uint4 *>(bytes + start);
+    const int units = (int)((end - start) / 16);
+    uint32_t cnt = 0, high = 0;
+    int u = 0;
+    for (; u + 4 <= units; u += 4) {       // 64-byte bursts: with next to no work per byte this is the fastest feed
+        uint4 v[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) v[i] = src[u + i];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                uint32_t x = w[j] ^ 0x0a0a0a0au;                                        // zero byte <=> '\n'
+                uint32_t z = ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu);    // exact zero-byte test
+                cnt += __popc(z);
+                high |= w[j];
+            }
+        }
+    }
+    for (size_t p = start + (size_t)u * 16; p < end; p++) { cnt += bytes[p] == '\n'; high |= bytes[p]; }
+    // bit 31: the stripe ends on a '\n', i.e. the next stripe starts a fresh line (the scan moves it to bit 63 of
+    // that stripe's base, so the match kernels need not probe the byte before their stripe)
+    counts[g] = cnt | (bytes[end - 1] == '\n' ? kEndsOnNewline : 0u);
+    if (high & 0x80808080u) atomicOr(flags, 1u);
+}
+
+// bytes[i] = bit i of the accept bitmap (the byte-per-line form of the result)
+__global__ __launch_bounds__(256) void expand_bits_kernel(const uint32_t *__restrict__ bits, size_t nlines, uint8_t *__restrict__ out) {
+    const size_t w = (size_t)blockIdx.x * 256 + threadIdx.x;          // one 32-line word -> 32 bytes
+    if (w * 32 >= nlines) return;
+    const uint32_t v = bits[w];
+    if (w * 32 + 32 <= nlines) {
+        uint4 o[2];
+        uint32_t *p = reinterpret_cast<uint32_t *>(o);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            uint32_t n = (v >> (4 * j)) & 0xfu;
+            p[j] = (n & 1u) | ((n & 2u) << 7) | ((n & 4u) << 14) | ((n & 8u) << 21);
+        }
+        uint4 *dst = reinterpret_cast<uint4 *>(out + w * 32);
+        dst[0] = o[0]; dst[1] = o[1];
+    } else {
+        for (size_t i = w * 32; i < nlines; i++) out[i] = (uint8_t)((v >> (i & 31)) & 1u);
+    }
+}
+
+// exclusive scan of n counts into n+1 bases, two levels: (1) every workgroup sums its chunk of kScanChunk
+// counts; (2) one workgroup scans the chunk sums; (3) every workgroup scans its chunk from its chunk base.
+constexpr int kScanChunk = 4096;
+__global__ __launch_bounds__(256) void scan_chunk_sums_kernel(const uint32_t *__restrict__ counts, size_t n, uint64_t *__restrict__ sums) {
+    __shared__ uint64_t part[4];
+    const size_t lo = (size_t)blockIdx.x * kScanChunk;
+    uint64_t s = 0;
+    for (size_t i = lo + threadIdx.x; i < lo + kScanChunk && i < n; i += 256) s += counts[i] & kCountMask;
+#pragma unroll
+    for (int d = 32; d; d >>= 1) s += __shfl_down(s, d, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
+}
+__global__ __launch_bounds__(1024) void scan_sums_kernel(uint64_t *__restrict__ sums, size_t nchunks, uint64_t *__restrict__ total) {
+    __shared__ uint64_t sh[1024];
+    const size_t per = (nchunks + 1023) / 1024;
+    const size_t lo = threadIdx.x * per < nchunks ? threadIdx.x * per : nchunks, hi = lo + per < nchunks ? lo + per : nchunks;
+    uint64_t s = 0;
+    for (size_t i = lo; i < hi; i++) s += sums[i];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t run = 0;
+        for (int i = 0; i < 1024; i++) { uint64_t v = sh[i]; sh[i] = run; run += v; }
+        *total = run;
+    }
+    __syncthreads();
+    uint64_t run = sh[threadIdx.x];
+    for (size_t i = lo; i < hi; i++) { uint64_t v = sums[i]; sums[i] = run; run += v; }
+}
+__global__ __launch_bounds__(256) void scan_chunks_kernel(const uint32_t *__restrict__ counts, size_t n, const uint64_t *__restrict__ sums,
+                                                           uint64_t *__restrict__ base) {
+    __shared__ uint64_t sh[256];
+    const size_t lo = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * (kScanChunk / 256);
+    uint64_t s = 0;
+    for (size_t i = lo; i < lo + kScanChunk / 256 && i < n; i++) s += counts[i] & kCountMask;
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t run = sums[blockIdx.x];
+        for (int i = 0; i < 256; i++) { uint64_t v = sh[i]; sh[i] = run; run += v; }
+    }
+    __syncthreads();
+    uint64_t run = sh[threadIdx.x];
+    for (size_t i = lo; i < lo + kScanChunk / 256 && i < n; i++) {
+        const bool fresh = i == 0 || (counts[i - 1] & kEndsOnNewline);
+        base[i] = run | (fresh ? kFreshStripe : 0);
+        run += counts[i] & kCountMask;
+    }
+}
+
+// ============================================================================================ search
+// Two kernels.  line_offsets_kernel (once per corpus): lane = stripe, every '\n' at p inside the stripe starts the next
+// line at p + 1 (line numbers from the stripe index).  search_lines_kernel: lane = line.  Step the forward DFA until it
+// accepts (that is the smallest match end e) and stop there - a lane never reads the rest of its line - then walk the
+// reverse DFA back from e to the line start, remembering the last position where it accepts (the smallest start of a
+// match that ends at e).  Consecutive lanes own consecutive lines: their text is contiguous and both result arrays are
+// written coalesced.
+__global__ __launch_bounds__(256) void line_offsets_kernel(const uint8_t *__restrict__ bytes, size_t nbytes, uint32_t stripe,
+                                                           const uint64_t *__restrict__ stripe_base, size_t nstripes,
+                                                           uint64_t *__restrict__ line_off) {
+    const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= nstripes) return;
+    const size_t start = g * (size_t)stripe, end = start + stripe < nbytes ? start + stripe : nbytes;
+    uint64_t line = line_of(stripe_base[g]);             // index of the line that contains my first byte
+    if (g == 0) line_off[0] = 0;
+    size_t pos = start;
+    for (; pos + 16 <= end; pos += 16) {                 // stripes start 16-byte aligned
+        const uint4 v = *reinterpret_cast<const uint4 *>(bytes + pos);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint32_t x = w[j] ^ 0x0a0a0a0au;
+            uint32_t hit = (x - 0x01010101u) & ~x & 0x80808080u;        // exact for the lowest flagged byte; refined below
+            while (hit) {
+                const int k = (__ffs((int)hit) - 1) >> 3;
+                if (((w[j] >> (8 * k)) & 0xffu) == '\n') line_off[++line] = pos + 4 * j + k + 1;
+                hit &= hit - 1;
+            }
+        }
+    }
+    for (; pos < end; pos++)
+        if (bytes[pos] == '\n') line_off[++line] = pos + 1;
+}
+
+struct SearchTables {
+    const uint8_t *cls;
+    const uint16_t *next_f, *next_r;                     // bit 15 of an entry = the state it leads to is accepting
+    uint32_t K, start_f, start_r;
+    bool empty_matches;
+    __device__ void load(const SearchDevice &p, uint8_t *lds) {
+        uint16_t *nf = reinterpret_cast<uint16_t *>(lds);
+        uint16_t *nr = nf + (size_t)p.nf * p.ncls;
+        uint8_t *c = reinterpret_cast<uint8_t *>(nr + (size_t)p.nr * p.ncls);
+        for (uint32_t i = threadIdx.x; i < p.nf * p.ncls; i += blockDim.x) { const uint16_t t = p.next_f[i]; nf[i] = (uint16_t)(t | (p.acc_f[t] ? 0x8000u : 0u)); }
+        for (uint32_t i = threadIdx.x; i < p.nr * p.ncls; i += blockDim.x) { const uint16_t t = p.next_r[i]; nr[i] = (uint16_t)(t | (p.acc_r[t] ? 0x8000u : 0u)); }
+        for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) c[i] = p.cls[i];
+        cls = c; next_f = nf; next_r = nr; K = p.ncls; start_f = p.start_f; start_r = p.start_r;
+        empty_matches = p.acc_f[p.start_f] != 0;
+    }
+};
+// First match of bytes[p, b) whose start is >= p: false if there is none.  s, e are absolute offsets.
+__device__ __forceinline__ bool search_from(const SearchTables &t, const uint8_t *__restrict__ bytes, size_t nbytes, size_t p, size_t b,
+                                            size_t &s, size_t &e) {
+    if (t.empty_matches) { s = p; e = p; return true; }          // the pattern accepts "": the match is [p, p)
+    uint32_t q = t.start_f;
+    size_t pos = p;
+    bool found = false;
+    while (pos < b && !found) {                                   // aligned dwords; bytes before `pos` / from `b` on are skipped
+        const size_t base = pos & ~(size_t)3;
+        uint32_t w;
+        if (base + 4 <= nbytes) w = *reinterpret_cast<const uint32_t *>(bytes + base);
+        else { w = 0; for (size_t k = pos; k < nbytes; k++) w |= (uint32_t)bytes[k] << (8 * (k - base)); }     // last dword of the data
+        const size_t stop = base + 4 < b ? base + 4 : b;
+        for (; pos < stop; pos++) {
+            const uint32_t x = t.next_f[q * t.K + t.cls[(w >> (8 * (pos - base))) & 0xffu]];
+            q = x & 0x7fffu;
+            if (x & 0x8000u) { found = true; pos++; break; }
+        }
+    }
+    if (!found) return false;
+    e = pos;
+    uint32_t r = t.start_r;
+    size_t best = pos;
+    for (size_t k = pos; k > p;) {
+        k--;
+        const uint32_t x = t.next_r[r * t.K + t.cls[bytes[k]]];
+        r = x & 0x7fffu;
+        if (!r) break;                                            // state 0 is dead
+        if (x & 0x8000u) best = k;
+    }
+    s = best;
+    return true;
+}
+__global__ __launch_bounds__(256) void search_lines_kernel(SearchDevice prog, const uint8_t *__restrict__ bytes, size_t nbytes,
+                                                           const uint64_t *__restrict__ line_off, size_t nlines,
+                                                           uint32_t *__restrict__ match_start, uint32_t *__restrict__ match_end) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    SearchTables t;
+    t.load(prog, smem);
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nlines) return;
+    const size_t a = line_off[i], b = line_off[i + 1] - 1;        // [a, b): the line without its '\n'
+    size_t s, e;
+    const bool found = search_from(t, bytes, nbytes, a, b, s, e);
+    match_start[i] = found ? (uint32_t)(s - a) : 0xffffffffu;
+    match_end[i] = found ? (uint32_t)(e - a) : 0xffffffffu;
+}
+// All matches of a line, left to right: after a match the search continues at its end (one byte further after an empty
+// match).  FILL = false: count[i] = number of matches.  FILL = true: the matches of line i go to slots first[i], ...
+template <bool FILL>
+__global__ __launch_bounds__(256) void search_all_kernel(SearchDevice prog, const uint8_t *__restrict__ bytes, size_t nbytes,
+                                                         const uint64_t *__restrict__ line_off, size_t nlines,
+                                                         uint32_t *__restrict__ count, const uint64_t *__restrict__ first,
+                                                         uint32_t *__restrict__ match_start, uint32_t *__restrict__ match_end) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    SearchTables t;
+    t.load(prog, smem);
+    __syncthreads();
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nlines) return;
+    const size_t a = line_off[i], b = line_off[i + 1] - 1;
+    uint64_t slot = FILL ? first[i] : 0;
+    uint32_t k = 0;
+    for (size_t p = a; p <= b;) {
+        size_t s, e;
+        if (!search_from(t, bytes, nbytes, p, b, s, e)) break;
+        if (FILL) { match_start[slot + k] = (uint32_t)(s - a); match_end[slot + k] = (uint32_t)(e - a); }
+        k++;
+        p = e > s ? e : e + 1;
+    }
+    if (!FILL) count[i] = k;
+}
+
+// ============================================================================================ one long string
+// Chunk maps.  LDS: the plain DFA widened to one u16 entry per (state, byte value 0..127 | >= 0x80), entry = row
+// offset of the next state (state * 129), so a step is one clamp, one add and one ds_read_u16.
+constexpr int kLongThreads = 256;
+__global__ __launch_bounds__(kLongThreads) void long_maps_kernel(DfaDevice p, const uint8_t *__restrict__ bytes, size_t nbytes, uint32_t chunk,
+                                                                 uint32_t nchunks, uint16_t *__restrict__ maps) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t *wide = reinterpret_cast<uint16_t *>(smem);
+    const uint32_t D = p.nstates;
+    for (uint32_t i = threadIdx.x; i < D * kWideColumns; i += kLongThreads) {
+        const uint32_t s = i / kWideColumns, c = i % kWideColumns;
+        wide[i] = (uint16_t)(p.next[s * p.ncls + p.cls[c]] * kWideColumns);     // column 128 stands for every byte >= 0x80
+    }
+    __syncthreads();
+    const uint32_t per_block = kLongThreads / D, ci = threadIdx.x / D, s0 = threadIdx.x % D;
+    const size_t k = (size_t)blockIdx.x * per_block + ci;
+    if (ci >= per_block || k >= nchunks) return;
+    const size_t a = k * (size_t)chunk, b = a + chunk < nbytes ? a + chunk : nbytes;
+    uint32_t row = s0 * kWideColumns;
+    size_t pos = a;
+    if ((reinterpret_cast<uintptr_t>(bytes) & 15) == 0) {                       // chunk starts are multiples of 16
+        for (; pos + 16 <= b; pos += 16) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(bytes + pos);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const uint32_t c = (w[i >> 2] >> (8 * (i & 3))) & 0xffu;
+                row = wide[row + (c < 128 ? c : 128)];
+            }
+        }
+    }
+    for (; pos < b; pos++) {
+        const uint32_t c = bytes[pos];
+        row = wide[row + (c < 128 ? c : 128)];
+    }
+    maps[k * D + s0] = (uint16_t)(row / kWideColumns);
+}
+// out[g] = in[g*group + group-1] o ... o in[g*group]   (one lane per start state; dependent L2 reads)
+__global__ __launch_bounds__(kLongThreads) void long_compose_kernel(const uint16_t *__restrict__ in, uint32_t nin, uint32_t D, uint32_t group,
+                                                                    uint16_t *__restrict__ out) {
+    const uint32_t j = threadIdx.x;
+    if (j >= D) return;
+    const size_t lo = (size_t)blockIdx.x * group, hi = lo + group < nin ? lo + group : nin;
+    uint32_t s = j;
+    for (size_t k = lo; k < hi; k++) s = in[k * D + s];
+    out[(size_t)blockIdx.x * D + j] = (uint16_t)s;
+}
+__global__ void long_finish_kernel(const uint16_t *__restrict__ map, DfaDevice p, uint8_t *__restrict__ accept) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) accept[0] = p.acc[map[p.start]];
+}
+
+}  // namespace
+
+int count_newlines_per_stripe(const uint8_t *bytes, size_t nbytes, uint32_t stripe, uint32_t *counts, size_t nstripes, uint32_t *flags,
+                              void *stream) {
+    if (!nstripes) return 0;
+    size_t blocks = (nstripes + 255) / 256;
+    hipLaunchKernelGGL(count_newlines_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, bytes, nbytes, stripe, counts, nstripes, flags);
+    return (int)hipGetLastError();
+}
+int expand_bits(const uint32_t *bits, size_t nlines, uint8_t *out, void *stream) {
+    if (!nlines) return 0;
+    size_t words = (nlines + 31) / 32, blocks = (words + 255) / 256;
+    hipLaunchKernelGGL(expand_bits_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, bits, nlines, out);
+    return (int)hipGetLastError();
+}
+int scan_counts(const uint32_t *counts, uint64_t *base, uint64_t *chunk_sums, size_t n, void *stream) {
+    const size_t nchunks = (n + kScanChunk - 1) / kScanChunk;
+    hipStream_t st = (hipStream_t)stream;
+    if (nchunks) hipLaunchKernelGGL(scan_chunk_sums_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, counts, n, chunk_sums);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, st, chunk_sums, nchunks, base + n);
+    if (nchunks) hipLaunchKernelGGL(scan_chunks_kernel, dim3((unsigned)nchunks), dim3(256), 0, st, counts, n, chunk_sums, base);
+    return (int)hipGetLastError();
+}
+size_t scan_scratch_words(size_t n) { return (n + kScanChunk - 1) / kScanChunk + 1; }
+
+int match_stripes_dfa(const LineDfaDevice &p, bool clamp_high, const uint8_t *bytes, size_t nbytes, uint32_t stripe,
+                      const uint64_t *stripe_base, size_t nstripes, uint32_t *accept, void *stream) {
+#define GO(WIDE, CLAMP) launch_stripes<LineDfaEngine<WIDE, CLAMP>, LineDfaDevice>(p, LineDfaEngine<WIDE, CLAMP>::lds_bytes(p), bytes, nbytes, stripe, stripe_base, nstripes, accept, stream)
+    if (p.in_global) return launch_stripes<LineDfaGlobalEngine, LineDfaDevice>(p, 256, bytes, nbytes, stripe, stripe_base, nstripes, accept, stream);
+    if (p.wide) return clamp_high ? GO(true, true) : GO(true, false);
+    return GO(false, false);
+#undef GO
+}
+int match_stripes_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
+                       size_t nstripes, uint32_t *accept, void *stream) {
+    if (!nstripes) return 0;
+    if (Dfa2::lds_bytes(p) > kDfa2MaxTable) return (int)hipErrorInvalidValue;
+    size_t blocks = (nstripes + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(match_stripes2_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept);
+    return (int)hipGetLastError();
+}
+// byte-stride table engines in one-pass mode (bytes >= 0x80 are always clamped: nobody has looked at the corpus yet)
+int match_onepass_dfa(const LineDfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, size_t nstripes, uint32_t *counts,
+                      uint32_t *slabs, void *stream) {
+    if (p.in_global) return launch_onepass<LineDfaGlobalEngine, LineDfaDevice>(p, 256, bytes, nbytes, stripe, nstripes, counts, slabs, stream);
+    if (p.wide) return launch_onepass<LineDfaEngine<true, true>, LineDfaDevice>(p, LineDfaEngine<true, true>::lds_bytes(p), bytes, nbytes, stripe, nstripes, counts, slabs, stream);
+    return launch_onepass<LineDfaEngine<false, false>, LineDfaDevice>(p, LineDfaEngine<false, false>::lds_bytes(p), bytes, nbytes, stripe, nstripes, counts, slabs, stream);
+}
+size_t onepass_slab_words(size_t nstripes, uint32_t stripe) {
+    return ((nstripes + kThreads - 1) / kThreads) * slab_words_per_lane(stripe) * kThreads;
+}
+int match_onepass_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, size_t nstripes, uint32_t *counts,
+                       uint32_t *slabs, void *stream) {
+    if (!nstripes) return 0;
+    if (Dfa2::lds_bytes(p) > kDfa2MaxTable) return (int)hipErrorInvalidValue;
+    size_t blocks = (nstripes + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(match_stripes2_onepass_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, p, bytes, nbytes, stripe, counts, slabs);
+    return (int)hipGetLastError();
+}
+int compact_streams(const uint32_t *counts, const uint64_t *stripe_base, size_t nstripes, uint32_t stripe, const uint32_t *slabs,
+                    uint32_t *accept_bits, size_t cap_words, uint32_t *overflow, void *stream) {
+    if (!nstripes) return 0;
+    hipLaunchKernelGGL(compact_streams_kernel, dim3((unsigned)((nstripes + 255) / 256)), dim3(256), 0, (hipStream_t)stream, counts, stripe_base, nstripes,
+                       stripe, slabs, accept_bits, cap_words, overflow);
+    return (int)hipGetLastError();
+}
+size_t search_lds_bytes(const SearchDevice &p) { return ((size_t)p.nf + p.nr) * p.ncls * sizeof(uint16_t) + 256; }
+int build_line_offsets(const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base, size_t nstripes,
+                       uint64_t *line_off, void *stream) {
+    if (!nstripes) return 0;
+    hipLaunchKernelGGL(line_offsets_kernel, dim3((unsigned)((nstripes + 255) / 256)), dim3(256), 0, (hipStream_t)stream, bytes, nbytes, stripe,
+                       stripe_base, nstripes, line_off);
+    return (int)hipGetLastError();
+}
+int search_lines(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *line_off, size_t nlines, uint32_t *match_start,
+                 uint32_t *match_end, void *stream) {
+    if (!nlines) return 0;
+    const size_t lds = search_lds_bytes(p);
+    if (lds > kSearchLdsBudget || p.nf > 32767 || p.nr > 32767) return (int)hipErrorInvalidValue;
+    static LdsAttr attr;
+    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(search_lines_kernel), lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(search_lines_kernel, dim3((unsigned)((nlines + 255) / 256)), dim3(256), lds, (hipStream_t)stream, p, bytes, nbytes, line_off, nlines,
+                       match_start, match_end);
+    return (int)hipGetLastError();
+}
+int search_all(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *line_off, size_t nlines, uint32_t *count,
+               const uint64_t *first, uint32_t *match_start, uint32_t *match_end, void *stream) {
+    if (!nlines) return 0;
+    const size_t lds = search_lds_bytes(p);
+    if (lds > kSearchLdsBudget || p.nf > 32767 || p.nr > 32767) return (int)hipErrorInvalidValue;
+    const bool fill = first != nullptr;
+    static LdsAttr attr_fill, attr_count;
+    hipError_t e = fill ? ensure_dynamic_lds(attr_fill, reinterpret_cast<const void *>(search_all_kernel<true>), lds)
+                        : ensure_dynamic_lds(attr_count, reinterpret_cast<const void *>(search_all_kernel<false>), lds);
+    if (e != hipSuccess) return (int)e;
+    const dim3 grid((unsigned)((nlines + 255) / 256));
+    if (fill) hipLaunchKernelGGL(search_all_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, p, bytes, nbytes, line_off, nlines, count, first, match_start, match_end);
+    else hipLaunchKernelGGL(search_all_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, p, bytes, nbytes, line_off, nlines, count, first, match_start, match_end);
+    return (int)hipGetLastError();
+}
+static uint32_t long_chunk(size_t nbytes) {
+    uint32_t chunk = 1024;                                     // at most 65536 chunks, of 1 KiB or more
+    while (((nbytes + chunk - 1) / chunk) > 65536) chunk <<= 1;
+    return chunk;
+}
+size_t long_scratch_bytes(uint32_t nstates, size_t nbytes, uint32_t *chunk) {
+    *chunk = long_chunk(nbytes);
+    const size_t k0 = (nbytes + *chunk - 1) / *chunk, k1 = (k0 + kLongGroup - 1) / kLongGroup;
+    return (k0 + k1 + 2) * nstates * sizeof(uint16_t);         // level 0, then the levels ping-pong between two areas
+}
+int match_long_dfa(const DfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t chunk, void *scratch, uint8_t *accept,
+                   void *stream) {
+    const uint32_t D = p.nstates;
+    if (!D || D > kLongMaxStates || !nbytes) return (int)hipErrorInvalidValue;
+    const size_t lds = (size_t)D * kWideColumns * sizeof(uint16_t);
+    static LdsAttr attr;
+    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(long_maps_kernel), lds);
+    if (e != hipSuccess) return (int)e;
+    uint32_t n = (uint32_t)((nbytes + chunk - 1) / chunk);
+    uint16_t *cur = static_cast<uint16_t *>(scratch), *other = cur + (size_t)n * D;
+    const uint32_t per_block = kLongThreads / D;
+    hipLaunchKernelGGL(long_maps_kernel, dim3((n + per_block - 1) / per_block), dim3(kLongThreads), lds, (hipStream_t)stream, p, bytes, nbytes,
+                       chunk, n, cur);
+    uint16_t *area[2] = {other, cur};                          // level 1 writes behind level 0, level 2 over level 0, ...
+    for (int lvl = 0; n > 1; lvl++) {
+        const uint32_t m = (n + kLongGroup - 1) / kLongGroup;
+        uint16_t *dst = area[lvl & 1];
+        hipLaunchKernelGGL(long_compose_kernel, dim3(m), dim3(kLongThreads), 0, (hipStream_t)stream, cur, n, D, kLongGroup, dst);
+        cur = dst;
+        n = m;
+    }
+    hipLaunchKernelGGL(long_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cur, p, accept);
+    return (int)hipGetLastError();
+}
+int match_extents_dfa(const DfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim, uint8_t *accept,
+                      void *stream) {
+    // tables beyond the LDS budget (the batch kernel's "global" form) stay in HBM/L2 here too
+    if (PlainDfaEngine::lds_bytes(p) > kPlainDfaLdsBudget)
+        return launch_extents<PlainDfaGlobalEngine, DfaDevice>(p, PlainDfaGlobalEngine::lds_bytes(p), bytes, off, nitems, trim, accept, stream);
+    return launch_extents<PlainDfaEngine, DfaDevice>(p, PlainDfaEngine::lds_bytes(p), bytes, off, nitems, trim, accept, stream);
+}
+
+}  // namespace dev
+}  // namespace rrx

@@ -31,11 +31,14 @@ def test_corpus_argument_validation_happens_before_any_device_call():
 
 
 def test_oversized_automata_are_refused_quickly():
-    # > 4096 positions and an exploding subset construction: no engine admits it (RRX_ERR_UNSUPPORTED)
+    # beyond the front end's 65536 reference states: refused before any lowering is tried
     t0 = time.time()
-    with pytest.raises(rr.RRegexError, match="too large"):
-        rr.RRegex("(a|b)*a(a|b){5000}")
+    with pytest.raises(rr.RRegexError, match="too many states"):
+        rr.RRegex("(a|b)*a(a|b){20000}")
     assert time.time() - t0 < 20
+    # > 4096 positions and an exploding subset construction: only the block-cooperative engine admits it
+    with pytest.raises(rr.RRegexError, match="too large"):
+        rr.RRegex("(a|b)*a(a|b){5000}", rr.ENGINE_NFA_WAVE)
     # forcing an engine that cannot hold the automaton is refused as well
     with pytest.raises(rr.RRegexError, match="too large"):
         rr.RRegex("(a|b)*a(a|b){600}", rr.ENGINE_NFA)
@@ -49,4 +52,5 @@ def test_engine_selection_ladder():
     assert rr.RRegex("a{1,300}", rr.ENGINE_DFA).engine_name == "dfa-classed-table"
     assert rr.RRegex("(a|b)*a(a|b){40}").engine_name == "nfa-shift-and"           # 2^41 subsets, 44 positions
     assert rr.RRegex("(a|b)*a(a|b){600}").engine_name == "nfa-group-cooperative"
+    assert rr.RRegex("(a|b)*a(a|b){40}", rr.ENGINE_NFA_BLOCK).engine_name == "nfa-block-cooperative"
     assert rr.RRegex("abc", rr.ENGINE_DFA_GLOBAL).engine_name == "dfa-global-table"
