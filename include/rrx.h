@@ -60,6 +60,9 @@ int         rrx_accepts_empty(const rrx_regex *re); /* Processor::operator*() on
  * layout); 0 if that form was not built.                                                                      */
 #define RRX_PROGRAM_SEARCH_FWD 6   /* "any bytes, then the pattern": accepting where a match ends              */
 #define RRX_PROGRAM_SEARCH_REV 7   /* the pattern right to left: accepting where a match starts                */
+#define RRX_PROGRAM_SEARCH_LINE 9  /* the forward table as the stripe-wise search kernel runs it: [nrows, ncols, start row,
+                                      SKIP row, column of byte[256], entry[nrows][ncols]], entry = next row | '\n' << 16 |
+                                      hit << 17 | match-starts-at-the-line-start << 18 (0 words: form not available)   */
 size_t rrx_program_words(const rrx_regex *re, int kind, uint32_t *out, size_t cap);
 
 /* ---- batch of strings: the replacement for calling get_acceptance_iter(line)++ per string ------------ *

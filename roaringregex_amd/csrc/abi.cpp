@@ -40,6 +40,7 @@ struct DeviceTables {
 struct SearchTablesOnDevice {
     void *blob = nullptr;
     dev::SearchDevice dev;
+    dev::SearchChunkDevice chunk;      // the stripe-wise form (forward table in line mode); nrows = 0: not usable
 };
 
 int instantiated_width(uint32_t W) { return W <= 4 ? (int)W : W <= 6 ? 6 : W <= 8 ? 8 : W <= 12 ? 12 : 16; }
@@ -67,6 +68,7 @@ struct rrx_regex {
     // search (built on first use): the forward "anything, then the pattern" DFA and the reverse DFA
     mutable int search_state = 0;        // 0 = not built, 1 = built, -1 = does not fit
     mutable DfaProgram search_fwd, search_rev;
+    mutable SearchLineProgram search_line;  // stripe-wise form (nrows = 0: not built)
     mutable std::map<int, SearchTablesOnDevice> search_on_device;
     // Scratch of the single-string entries (rrx_match_string / rrx_match_cstr): one grow-only device buffer per device,
     // kept across calls (a hipMalloc + hipFree pair per string cost more than the match itself).  `scratch_mu` is held
@@ -113,6 +115,9 @@ struct rrx_regex {
         if (search_state == 0) {
             const Reduced red = reduce(trimmed);
             const bool ok = search_dfas(red, kMaxSubsetStates, search_fwd, search_rev);
+            DfaProgram anchored;
+            if (!(ok && lower_dfa(red, kMaxSubsetStates, anchored) && lower_search_line(search_fwd, anchored, 16383, search_line)))
+                search_line = SearchLineProgram();
             dev::SearchDevice probe;
             probe.nf = search_fwd.nstates; probe.nr = search_rev.nstates; probe.ncls = search_fwd.ncls;
             search_state = ok && dev::search_lds_bytes(probe) <= dev::kSearchLdsBudget && probe.nf <= 32767 && probe.nr <= 32767 ? 1 : -1;
@@ -132,6 +137,32 @@ struct rrx_regex {
         const size_t oNF = put(search_fwd.next.data(), search_fwd.next.size() * 2), oNR = put(search_rev.next.data(), search_rev.next.size() * 2);
         const size_t oAF = put(search_fwd.accepting.data(), search_fwd.accepting.size()), oAR = put(search_rev.accepting.data(), search_rev.accepting.size());
         SearchTablesOnDevice t;
+        // The stripe-wise form (lower_search_line): row indices become byte offsets, flags move to byte 2 of the entry:
+        // bit 0 = '\n', bit 1 = hit, and for a hit bit 0 = anchored (flag values 1 = '\n', 2 = hit, 3 = hit, match starts
+        // at the line start).
+        size_t oTL = 0, oC4 = 0, oRV = 0;
+        const uint32_t K = search_fwd.ncls, NR = search_rev.nstates;
+        const bool line_form = search_line.nrows && (size_t)search_line.nrows * search_line.ncols * 4 <= 65535 - 512 && K < 128;
+        if (line_form) {
+            const uint32_t row_bytes = search_line.ncols * 4;
+            std::vector<uint32_t> T(search_line.table.size());
+            for (size_t i = 0; i < T.size(); i++) {
+                const uint32_t v = search_line.table[i];
+                const uint32_t flags = (v & kSearchNewline) ? 1u : (v & kSearchHit) ? ((v & kSearchAnchored) ? 3u : 2u) : 0u;
+                T[i] = (v & 0xffffu) * row_bytes | flags << 16;
+            }
+            uint16_t c4[256];
+            for (int c = 0; c < 256; c++) c4[c] = (uint16_t)(search_fwd.cls[c] * 4);
+            c4['\n'] = (uint16_t)(K * 4);
+            std::vector<uint16_t> rv(((size_t)NR * K + 1) & ~(size_t)1, 0);
+            for (size_t i = 0; i < (size_t)NR * K; i++) { const uint16_t nx = search_rev.next[i]; rv[i] = (uint16_t)(nx | (search_rev.accepting[nx] ? 0x8000u : 0u)); }
+            oTL = put(T.data(), T.size() * 4);
+            oC4 = put(c4, sizeof c4);
+            oRV = put(rv.data(), rv.size() * 2);
+            t.chunk.nrows = search_line.nrows; t.chunk.stride = search_line.ncols;
+            t.chunk.start_off = search_line.start * row_bytes; t.chunk.skip_off = search_line.skip * row_bytes;
+            t.chunk.nr = NR; t.chunk.ncls = K; t.chunk.start_r = search_rev.start;
+        }
         HIP_TRY(hipMalloc(&t.blob, host.size()));
         hipError_t e = hipMemcpy(t.blob, host.data(), host.size(), hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipFree(t.blob); return hip_fail(e, "search table upload"); }
@@ -141,9 +172,22 @@ struct rrx_regex {
         t.dev.cls = base + oC;
         t.dev.next_f = reinterpret_cast<const uint16_t *>(base + oNF); t.dev.next_r = reinterpret_cast<const uint16_t *>(base + oNR);
         t.dev.acc_f = base + oAF; t.dev.acc_r = base + oAR;
+        if (line_form) {
+            t.chunk.T = reinterpret_cast<const uint32_t *>(base + oTL);
+            t.chunk.cls4 = reinterpret_cast<const uint16_t *>(base + oC4);
+            t.chunk.rev = reinterpret_cast<const uint16_t *>(base + oRV);
+            t.chunk.cls = base + oC;
+            if (dev::search_chunks_lds_bytes(t.chunk) > dev::kSearchChunkLdsBudget) t.chunk.nrows = 0;
+        }
         auto ins = search_on_device.emplace(device, t);
         *out = &ins.first->second.dev;
         return RRX_OK;
+    }
+    // the stripe-wise form of the same tables, or nullptr if they do not admit it (call after search_tables succeeded)
+    const dev::SearchChunkDevice *search_chunk_tables(int device) const {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = search_on_device.find(device);
+        return it != search_on_device.end() && it->second.chunk.nrows ? &it->second.chunk : nullptr;
     }
 
     // Upload the program for `device` once; returns the device-side descriptors.
@@ -343,6 +387,9 @@ struct rrx_corpus {
     // search only: offset of the first byte of every line, built on the first search of this corpus
     mutable std::mutex mu;
     mutable uint64_t *d_line_off = nullptr;     // [nlines + 1]
+    // stripe-wise search: newline prefix per search chunk (the stripe index itself when the stripe is that size)
+    mutable uint64_t *d_chunk_base = nullptr;   // [nchunks + 1 + scan scratch]; owned unless it aliases d_base
+    mutable size_t nchunks = 0;
 };
 
 static constexpr size_t kLongStringBytes = 32 * 1024;   // shorter single strings stay on one lane
@@ -443,6 +490,13 @@ size_t rrx_program_words(const rrx_regex *re, int kind, uint32_t *out, size_t ca
         const NfaProgram &p = re->nfa_block;
         w = {p.W, p.nbits, p.n_exc, p.accepts_empty ? 1u : 0u};
         for (auto *v : {&p.init, &p.fin, &p.chain, &p.self, &p.excm, &p.cgrp, &p.ctgt, &p.B, &p.xoff, &p.xtgt}) w.insert(w.end(), v->begin(), v->end());
+    } else if (kind == RRX_PROGRAM_SEARCH_LINE) {
+        std::lock_guard<std::mutex> lock(re->mu);
+        if (re->build_search() || !re->search_line.nrows) return 0;
+        const SearchLineProgram &d = re->search_line;
+        w = {d.nrows, d.ncols, d.start, d.skip};
+        for (int c = 0; c < 256; c++) w.push_back(c == '\n' ? d.ncols - 1 : re->search_fwd.cls[c]);
+        w.insert(w.end(), d.table.begin(), d.table.end());
     } else if (kind == RRX_ENGINE_DFA2 && re->has_dfa2) {
         const Dfa2Program &d = re->dfa2;
         w = {d.nstates, d.ncols, d.start, d.accepts_empty ? 1u : 0u};
@@ -523,6 +577,7 @@ void rrx_corpus_free(rrx_corpus *c) {
     if (c->d_counts) (void)hipFree(c->d_counts);
     if (c->d_base) (void)hipFree(c->d_base);
     if (c->d_line_off) (void)hipFree(c->d_line_off);
+    if (c->d_chunk_base && c->d_chunk_base != c->d_base) (void)hipFree(c->d_chunk_base);
     delete c;
 }
 
@@ -633,6 +688,28 @@ static int line_offsets(const rrx_corpus *c, void *stream) {
     return RRX_OK;
 }
 
+// newline prefix per search chunk (the granularity of the stripe-wise search kernel), built on the first search
+static int chunk_index(const rrx_corpus *c, void *stream) {
+    std::lock_guard<std::mutex> lock(c->mu);
+    if (c->d_chunk_base) return RRX_OK;
+    const size_t chunk = dev::search_chunk_bytes();
+    c->nchunks = (c->nbytes + chunk - 1) / chunk;
+    if (c->stripe == chunk) { c->d_chunk_base = c->d_base; return RRX_OK; }
+    uint32_t *counts = nullptr;
+    uint64_t *base = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(&counts), (c->nchunks + 1) * sizeof(uint32_t));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&base), (c->nchunks + 1 + dev::scan_scratch_words(c->nchunks)) * sizeof(uint64_t));
+    if (e == hipSuccess) e = hipMemsetAsync(counts + c->nchunks, 0, sizeof(uint32_t), (hipStream_t)stream);
+    int le = 0;
+    if (e == hipSuccess) le = dev::count_newlines_per_stripe(c->d_bytes, c->nbytes, (uint32_t)chunk, counts, c->nchunks, counts + c->nchunks, stream);
+    if (e == hipSuccess && !le) le = dev::scan_counts(counts, base, base + c->nchunks + 1, c->nchunks, stream);
+    if (e == hipSuccess && !le) e = hipStreamSynchronize((hipStream_t)stream);     // once per corpus: later searches may use other streams
+    if (counts) (void)hipFree(counts);
+    if (e != hipSuccess || le) { if (base) (void)hipFree(base); return e != hipSuccess ? hip_fail(e, "search chunk index") : hip_fail((hipError_t)le, "search chunk index launch"); }
+    c->d_chunk_base = base;
+    return RRX_OK;
+}
+
 int rrx_search_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_start, uint32_t *d_end, void *stream) {
     if (!re || !c || (c->nlines && (!d_start || !d_end))) return fail(RRX_ERR_ARG, "null argument");
     const dev::SearchDevice *t;
@@ -640,6 +717,13 @@ int rrx_search_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_star
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
     if (!c->nlines) return RRX_OK;
+    if (const dev::SearchChunkDevice *ct = re->search_chunk_tables(c->device)) {     // stripe-wise: one pass, coalesced results
+        rc = chunk_index(c, stream);
+        if (rc) return rc;
+        int e = dev::search_chunks(*ct, c->d_bytes, c->nbytes, c->d_chunk_base, c->nchunks, d_start, d_end, stream);
+        if (e) return hip_fail((hipError_t)e, "search_chunks launch");
+        return RRX_OK;
+    }
     rc = line_offsets(c, stream);
     if (rc) return rc;
     int e = dev::search_lines(*t, c->d_bytes, c->nbytes, c->d_line_off, c->nlines, d_start, d_end, stream);

@@ -164,6 +164,23 @@ struct SearchDevice {
     const uint8_t *acc_f = nullptr, *acc_r = nullptr;        // [n]
 };
 constexpr uint32_t kSearchLdsBudget = 64 * 1024;
+// Stripe-wise search (kernels_search.hip): the forward table in LINE MODE - one row per state plus the SKIP row (the line's
+// first match has been found: wait for '\n'), one column per byte class plus the '\n' column; entry = byte offset of the
+// next row (16 bits) | '\n' << 16 | hit << 17 (the byte completed the line's first match: next row = SKIP).
+struct SearchChunkDevice {
+    uint32_t nrows = 0, stride = 0, start_off = 0, skip_off = 0;
+    uint32_t nr = 0, ncls = 0, start_r = 0;
+    const uint32_t *T = nullptr;                 // [nrows][stride]
+    const uint16_t *cls4 = nullptr;              // [256] byte -> 4 * column
+    const uint16_t *rev = nullptr;               // [nr][ncls] reverse table, bit 15 = leads to an accepting state
+    const uint8_t *cls = nullptr;                // [256] byte -> class
+};
+constexpr size_t kSearchChunkLdsBudget = 80 * 1024;      // two workgroups per CU
+size_t search_chunk_bytes();                             // bytes of text per wave (the granularity of its newline index)
+size_t search_chunks_lds_bytes(const SearchChunkDevice &p);
+// chunk_base: per-chunk newline prefix in the stripe_base format (bit 63: the chunk begins at the start of a line)
+int search_chunks(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
+                  uint32_t *match_start, uint32_t *match_end, void *stream);
 size_t search_lds_bytes(const SearchDevice &p);
 // line_off[i] = offset of the first byte of line i (built once per corpus from the stripe index); nlines + 1 entries are
 // the caller's to size, entry nlines is written only when the corpus ends in '\n'.

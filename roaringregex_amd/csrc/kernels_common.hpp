@@ -50,11 +50,13 @@ struct TextRound {
     TextRound<N - 1> rest;
     __device__ __forceinline__ void load(const uint4 *p) { head = load_text(p); rest.load(p + 1); }
     template <class F> __device__ __forceinline__ void for_each_slot(F &&f) const { f(head); rest.for_each_slot(f); }
+    template <class F> __device__ __forceinline__ void for_each_slot_mut(F &&f) { f(head); rest.for_each_slot_mut(f); }
 };
 template <>
 struct TextRound<0> {
     __device__ __forceinline__ void load(const uint4 *) {}
     template <class F> __device__ __forceinline__ void for_each_slot(F &&) const {}
+    template <class F> __device__ __forceinline__ void for_each_slot_mut(F &&) {}
 };
 
 // ============================================================================================ batch kernel

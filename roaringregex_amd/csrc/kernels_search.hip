@@ -1,0 +1,369 @@
+// kernels_search.hip — stripe-wise search (rrx_search_corpus): for every line the accepted substring
+// with the smallest end, then the smallest start.  Shared device code: kernels_common.hpp.
+//
+// Geometry: a WAVE owns a contiguous chunk of 64 * S bytes, lane l its sub-stripe [l*S, (l+1)*S) (S = 128: one cache
+// line per lane, held in registers).  A line belongs to the lane its first byte lies in.  Per lane:
+//   1. forward pass over its S bytes with the line-mode forward table in LDS ("any bytes, then the pattern"; rows carry
+//      two flags: the byte was '\n' / the byte completed the first match of its line, after which the row is SKIP until
+//      the next '\n'): 2 LDS gathers and 4 VALU per byte, no branch - the flags are shifted into event words, 2 bits per
+//      byte;
+//   2. a wave prefix sum of the lanes' '\n' counts numbers the lines (the chunk's first line number comes from a per-chunk
+//      newline index, as the match kernel's stripes have);
+//   3. the events are replayed in byte order: a '\n' starts the next line, a hit walks the reverse table back from the
+//      match end to the line start (text re-read from L1/L2, 4 bytes per load) and leaves (start, end) in the wave's LDS
+//      staging array at the line's number;
+//   4. a lane whose last line is still undecided at the end of its sub-stripe follows it into the next lanes' bytes;
+//   5. the wave writes its lines' results, consecutive lanes consecutive lines: whole sectors, where one lane per stripe
+//      appending 8 bytes per line left them as partial writes (10 ms for the line offsets alone in the first version).
+#include "kernels_common.hpp"
+
+namespace rrx {
+namespace dev {
+namespace {
+
+constexpr int kSearchWaves = 8;                 // waves per workgroup (one table copy in LDS serves them)
+constexpr int kSearchS = 128;                   // bytes per lane
+constexpr uint32_t kSearchChunk = 64 * kSearchS;
+constexpr uint32_t kMaxStageLines = 1024;       // staged lines per wave (what the tables leave of the LDS budget, at most this); lines beyond go to memory directly
+constexpr uint32_t kNone = 0xffffffffu;
+
+typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
+typedef const __attribute__((address_space(3))) uint16_t *lds_u16_ptr;
+
+struct SearchLds {
+    const uint8_t *T;                           // forward line table, byte-addressed
+    const uint16_t *rev;                        // [nr][K], bit 15 = the state it leads to is accepting
+    const uint16_t *cls4;                       // [256] byte -> 4 * column of the forward table ('\n' -> its own column)
+    const uint8_t *cls;                         // [256] byte -> class (reverse table)
+    uint32_t K, start_r, start_off, skip_off;
+};
+
+// first byte position s in [lo, e] such that bytes[s, e) is accepted (e itself if only the empty string is: cannot
+// happen here, patterns that accept the empty string take another path)
+__device__ __forceinline__ size_t reverse_walk(const SearchLds &t, const uint8_t *__restrict__ bytes, size_t lo, size_t e) {
+    uint32_t r = t.start_r;
+    size_t best = e, k = e;
+    uint32_t w = 0;
+    bool have = false;
+    while (k > lo) {
+        k--;
+        if (!have || (k & 3) == 3) { w = *reinterpret_cast<const uint32_t *>(bytes + (k & ~(size_t)3)); have = true; }
+        const uint32_t c = (w >> (8 * (k & 3))) & 0xffu;
+        const uint32_t x = t.rev[r * t.K + t.cls[c]];
+        r = x & 0x7fffu;
+        if (!r) break;                                            // state 0 is dead
+        if (x & 0x8000u) best = k;
+    }
+    return best;
+}
+
+__global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void search_chunks_kernel(SearchChunkDevice prog, const uint8_t *__restrict__ bytes, size_t nbytes,
+                                                                          const uint64_t *__restrict__ chunk_base, size_t nchunks,
+                                                                          uint32_t *__restrict__ match_start, uint32_t *__restrict__ match_end,
+                                                                          uint32_t kStageLines) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // ---- tables into LDS, once per workgroup: its waves then take chunk after chunk (a chunk is only 8 KiB of text, the
+    // tables are up to 46 KiB).  The byte -> column table comes first, at LDS address 0, so that 2 * byte IS its address
+    // (checked below); the forward table's entries get the table's LDS address added: entry.word[0] + column = address.
+    const uint32_t t_words = prog.nrows * prog.stride, rev_words = (prog.nr * prog.ncls + 1) / 2;
+    uint32_t *C4 = reinterpret_cast<uint32_t *>(smem);            // 128 words
+    uint32_t *T = C4 + 128;
+    uint32_t *R = T + t_words;
+    uint32_t *C = R + rev_words;                                  // 64 words
+    uint32_t *stage = C + 64;                                     // [wave][2][kStageLines]
+    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem != 0u) __builtin_trap();
+    const uint32_t t_base = 512u;                                 // LDS address of T
+    for (uint32_t i = threadIdx.x; i < t_words; i += blockDim.x) T[i] = prog.T[i] + t_base;
+    for (uint32_t i = threadIdx.x; i < rev_words; i += blockDim.x) R[i] = reinterpret_cast<const uint32_t *>(prog.rev)[i];
+    for (uint32_t i = threadIdx.x; i < 128; i += blockDim.x) C4[i] = reinterpret_cast<const uint32_t *>(prog.cls4)[i];
+    for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x) C[i] = reinterpret_cast<const uint32_t *>(prog.cls)[i];
+    for (uint32_t i = threadIdx.x; i < kSearchWaves * 2 * kStageLines; i += blockDim.x) stage[i] = kNone;
+    __syncthreads();
+    SearchLds t;
+    t.T = smem; t.rev = reinterpret_cast<const uint16_t *>(R); t.cls4 = reinterpret_cast<const uint16_t *>(C4);
+    t.cls = reinterpret_cast<const uint8_t *>(C); t.K = prog.ncls; t.start_r = prog.start_r;
+    t.start_off = prog.start_off + t_base; t.skip_off = prog.skip_off + t_base;
+
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    uint32_t *st_s = stage + (size_t)wave * 2 * kStageLines, *st_e = st_s + kStageLines;
+    for (size_t chunk = (size_t)blockIdx.x * kSearchWaves + wave; chunk < nchunks; chunk += (size_t)gridDim.x * kSearchWaves) {
+    const size_t cstart = chunk * (size_t)kSearchChunk;
+    const size_t cend = cstart + kSearchChunk < nbytes ? cstart + kSearchChunk : nbytes;      // end of the chunk's data
+    const uint64_t cb = chunk_base[chunk];
+    const uint64_t base_line = line_of(cb);
+    const bool chunk_fresh = (cb & kFreshStripe) != 0;
+    const size_t my = cstart + (size_t)lane * kSearchS;
+    const size_t my_end = my + kSearchS < cend ? my + kSearchS : (my < cend ? cend : my);
+    const uint32_t vlen = (uint32_t)(my_end - my);                // my bytes: kSearchS except at the end of the corpus
+
+    auto step = [&](uint32_t &e, uint32_t c) -> uint32_t {        // -> flags: bit 0 = '\n', bit 1 = hit
+        e = *reinterpret_cast<lds_u32_ptr>((e & 0xffffu) + t.cls4[c]);
+        return (e >> 16) & 3u;
+    };
+
+    // ---- 1. forward pass over my bytes.  Lanes start in SKIP unless a line starts at their first byte.
+    const uint32_t last_byte = vlen ? bytes[my_end - 1] : 0u;
+    uint32_t prev_last = __shfl_up(last_byte, 1, 64);
+    const bool fresh = vlen && (lane == 0 ? chunk_fresh : prev_last == '\n');
+    uint32_t e = fresh ? t.start_off : t.skip_off;
+    constexpr int kEv = kSearchS / 16;
+    uint32_t ev[kEv];                                             // 2 bits per byte, the first byte of a word highest
+    {
+        // my 128 bytes in registers.  At the end of the corpus a lane holds fewer: whole 16-byte slots inside the data are
+        // loaded as such, the slot the data ends in byte by byte, the rest is zero; events behind the data are masked.
+        TextRound<kSearchS / 16> text;
+        if (vlen == kSearchS) text.load(reinterpret_cast<const uint4 *>(bytes + my));
+        else {
+            uint32_t off = 0;
+            text.for_each_slot_mut([&](uint4 &v) {
+                if (off + 16 <= vlen) v = *reinterpret_cast<const uint4 *>(bytes + my + off);
+                else {
+                    uint32_t w[4] = {0, 0, 0, 0};
+                    for (uint32_t k = off; k < vlen && k < off + 16; k++) w[(k - off) >> 2] |= (uint32_t)bytes[my + k] << (8 * ((k - off) & 3));
+                    v = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+                off += 16;
+            });
+        }
+        int slot = 0;
+        text.for_each_slot([&](const uint4 &v) {
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            uint32_t acc = 0;
+            // per byte: 2 * byte (SDWA) -> column offset (ds_read_u16) -> entry.word[0] + column (SDWA) -> entry
+            // (ds_read_b32) -> the two event bits shifted in: 4 VALU + 2 LDS.  The four column lookups of a text word do
+            // not depend on the state: they are issued together, ahead of the four dependent steps.  (asm volatile:
+            // left to itself the scheduler hoists all 128 column lookups of the round and spills their results.)
+#define RRX_SEARCH_COL(W, SEL, A, C)                                                                                              \
+            asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL : "=v"(A) : "v"(1u), "v"(W)); \
+            C = *reinterpret_cast<lds_u16_ptr>(A);
+#define RRX_SEARCH_STEP(C)                                                                                                        \
+            {                                                                                                                     \
+                uint32_t a_;                                                                                                      \
+                asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(a_) : "v"(e), "v"(C)); \
+                e = *reinterpret_cast<lds_u32_ptr>(a_);                                                                          \
+                acc <<= 2;                                                                                                        \
+                asm volatile("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(acc) : "v"(e), "v"(acc)); \
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint32_t a0, a1, a2, a3, c0, c1, c2, c3;
+                RRX_SEARCH_COL(w[q], "BYTE_0", a0, c0) RRX_SEARCH_COL(w[q], "BYTE_1", a1, c1)
+                RRX_SEARCH_COL(w[q], "BYTE_2", a2, c2) RRX_SEARCH_COL(w[q], "BYTE_3", a3, c3)
+                RRX_SEARCH_STEP(c0) RRX_SEARCH_STEP(c1) RRX_SEARCH_STEP(c2) RRX_SEARCH_STEP(c3)
+            }
+#undef RRX_SEARCH_STEP
+#undef RRX_SEARCH_COL
+            // (slot is a compile-time constant after inlining: the lambda is expanded once per slot)
+            ev[slot++] = acc;
+        });
+        if (vlen != kSearchS) {                                   // events behind the end of the data do not exist
+#pragma unroll
+            for (int i = 0; i < kEv; i++) {
+                const int valid = (int)vlen - 16 * i;             // bytes of this word inside the data
+                if (valid <= 0) ev[i] = 0;
+                else if (valid < 16) ev[i] &= ~0u << (2 * (16 - valid));
+            }
+        }
+    }
+    // ---- 2. number the lines: '\n' counts, prefix over the lanes
+    uint32_t nl = 0;
+#pragma unroll
+    for (int i = 0; i < kEv; i++) nl += __popc(ev[i] & ~(ev[i] >> 1) & 0x55555555u);      // fields equal to 1
+    uint32_t incl = nl;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+    const uint32_t total_nl = __shfl(incl, 63, 64);
+    uint32_t ord = incl - nl;                                     // ordinal (within the chunk) of the line my first byte is in
+
+    // ---- 3. my last line is still being searched at the end of my bytes (the row is not SKIP, the line did not end
+    // there): follow it into the next lanes' bytes until it is decided
+    size_t tail_end = 0;                                          // end of a match found that way
+    uint32_t tail_flags = 0;
+    if (vlen == kSearchS && (e & 0xffffu) != t.skip_off && last_byte != '\n' && (fresh || nl)) {
+        size_t pos = my_end;                                      // a multiple of 4
+        bool ended = false;
+        // sixteen bytes per load, the next sixteen requested before these are stepped (the loop is a chain of memory
+        // round trips otherwise: measured 40 % of the kernel); stepped like the forward pass, a text word at a time, the
+        // first event decides
+        uint4 cur = make_uint4(0, 0, 0, 0), nxt = cur;
+        if (pos + 16 <= nbytes) cur = *reinterpret_cast<const uint4 *>(bytes + pos);
+        while (pos + 16 <= nbytes && !ended) {
+            if (pos + 32 <= nbytes) nxt = *reinterpret_cast<const uint4 *>(bytes + pos + 16);
+            const uint32_t ww[4] = {cur.x, cur.y, cur.z, cur.w};
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                if (!ended) {
+                    const uint32_t w = ww[q];
+                    uint32_t acc = 0, a0, a1, a2, a3, c0, c1, c2, c3;
+#define RRX_SEARCH_COL(W, SEL, A, C)                                                                                              \
+                    asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL : "=v"(A) : "v"(1u), "v"(W)); \
+                    C = *reinterpret_cast<lds_u16_ptr>(A);
+#define RRX_SEARCH_STEP(C)                                                                                                        \
+                    {                                                                                                             \
+                        uint32_t a_;                                                                                              \
+                        asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(a_) : "v"(e), "v"(C)); \
+                        e = *reinterpret_cast<lds_u32_ptr>(a_);                                                                  \
+                        acc <<= 2;                                                                                                \
+                        asm volatile("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(acc) : "v"(e), "v"(acc)); \
+                    }
+                    RRX_SEARCH_COL(w, "BYTE_0", a0, c0) RRX_SEARCH_COL(w, "BYTE_1", a1, c1) RRX_SEARCH_COL(w, "BYTE_2", a2, c2) RRX_SEARCH_COL(w, "BYTE_3", a3, c3)
+                    RRX_SEARCH_STEP(c0) RRX_SEARCH_STEP(c1) RRX_SEARCH_STEP(c2) RRX_SEARCH_STEP(c3)
+#undef RRX_SEARCH_STEP
+#undef RRX_SEARCH_COL
+                    if (acc) {                                    // 2 bits per byte, byte 0 in bits 7..6
+                        const int z = (__clz((int)acc) - 24) >> 1;                // first byte with an event
+                        const uint32_t f = (acc >> (6 - 2 * z)) & 3u;
+                        if (f & 2u) { tail_end = pos + (size_t)(4 * q + z) + 1; tail_flags = f; }
+                        ended = true;                             // a hit, or the line's '\n'
+                    }
+                }
+            }
+            pos += 16;
+            cur = nxt;
+        }
+        for (; pos < nbytes && !ended; pos++) {                   // the last bytes of the corpus
+            const uint32_t f = step(e, bytes[pos]);
+            if (f & 2u) { tail_end = pos + 1; tail_flags = f; }
+            if (f) ended = true;
+        }
+    }
+    // ---- 4. replay the events in byte order (one loop body: the words rotate through ev[0]); the match found by
+    // following comes last.  A hit whose start is not known QUEUES a job (line start, match end, line number): walking
+    // back right here would make the lanes of a wave take turns, each waiting through the others' walks (measured: 33 ms
+    // for 8 GiB).  Positions are 32-bit offsets from the chunk start from here on.
+    auto emit = [&](uint32_t line_ord, uint32_t s_rel, uint32_t e_rel) {
+        if (line_ord < kStageLines) { st_s[line_ord] = s_rel; st_e[line_ord] = e_rel; }
+        else { match_start[base_line + line_ord] = s_rel; match_end[base_line + line_ord] = e_rel; }
+    };
+    constexpr int kJobs = 4;
+    uint32_t job_ls[kJobs], job_e[kJobs], job_ord[kJobs];         // slot 0 is the next to run
+    uint32_t njobs = 0;
+    bool owned = fresh, decided = false;                          // the current line: is it mine, has its match been found
+    const uint32_t my_rel = (uint32_t)(my - cstart), my_end_rel = (uint32_t)(my_end - cstart);
+    uint32_t ls = my_rel;                                         // its first byte (valid if owned)
+    uint32_t tail_rel = tail_end ? (uint32_t)(tail_end - cstart) : 0u;
+    uint32_t word_pos = my_rel;                                   // position of byte 0 of ev[0]
+    int words_left = kEv;
+    bool events_left = true;
+    while (events_left || njobs) {
+        // ---- 4a. events, until they run out or the job queue is full
+        while (events_left && njobs < kJobs) {
+            uint32_t f, pos;
+            if (ev[0]) {
+                const int z = __clz((int)ev[0]) >> 1;             // byte of the word, 0 = first
+                f = (ev[0] >> (30 - 2 * z)) & 3u;
+                ev[0] &= ~(3u << (30 - 2 * z));
+                pos = word_pos + (uint32_t)z;
+            } else if (words_left > 1) {
+                words_left--;
+                word_pos += 16;
+#pragma unroll
+                for (int i = 0; i + 1 < kEv; i++) ev[i] = ev[i + 1];
+                ev[kEv - 1] = 0;
+                continue;
+            } else if (tail_rel) {
+                f = tail_flags; pos = tail_rel - 1; tail_rel = 0;
+            } else { events_left = false; break; }
+            if (f == 1u) {                                        // '\n': the next line begins
+                if (owned && !decided && ord >= kStageLines) emit(ord, kNone, kNone);      // (staged lines default to "none")
+                ord++;
+                ls = pos + 1;
+                owned = ls < my_end_rel;                          // a line that starts at my_end is the next lane's
+                decided = false;
+            } else {                                              // the first match of my current line ends after this byte
+                if (owned) {
+                    if (f == 3u) emit(ord, 0u, pos + 1 - ls);     // the prefix itself is accepted: it starts at the line start
+                    else {
+#pragma unroll
+                        for (int j = 0; j < kJobs; j++)
+                            if ((uint32_t)j == njobs) { job_ls[j] = ls; job_e[j] = pos + 1; job_ord[j] = ord; }
+                        njobs++;
+                    }
+                }
+                decided = true;
+            }
+        }
+        // ---- 4b. walk back from every queued match end to its line start with the reverse table: smallest start.  Every
+        // lane runs through its own jobs back to back, one reverse step per turn of the loop (text re-read from L1/L2,
+        // four bytes per load, the next word requested one word ahead).
+        bool active = false;
+        size_t k = 0, lo = 0, best = 0, e_abs = 0;
+        uint32_t r = 0, w = 0, wn = 0, cur_ord = 0;
+        while (active || njobs) {
+            if (!active) {
+                lo = cstart + job_ls[0]; e_abs = cstart + job_e[0]; cur_ord = job_ord[0];
+#pragma unroll
+                for (int j = 0; j + 1 < kJobs; j++) { job_ls[j] = job_ls[j + 1]; job_e[j] = job_e[j + 1]; job_ord[j] = job_ord[j + 1]; }
+                njobs--;
+                k = e_abs; best = e_abs; r = t.start_r; active = true;
+                const size_t a0 = (k - 1) & ~(size_t)3;           // e_abs > lo: a match is never empty here
+                wn = *reinterpret_cast<const uint32_t *>(bytes + a0);
+                w = wn;
+                if (a0 >= 4 && a0 > lo) wn = *reinterpret_cast<const uint32_t *>(bytes + a0 - 4);
+            }
+            k--;
+            const uint32_t c = (w >> (8 * (k & 3))) & 0xffu;
+            const uint32_t x = t.rev[r * t.K + t.cls[c]];
+            r = x & 0x7fffu;
+            if (r && (x & 0x8000u)) best = k;
+            if (!r || k == lo) {                                  // dead, or at the line start: the job is done
+                emit(cur_ord, (uint32_t)(best - lo), (uint32_t)(e_abs - lo));
+                active = false;
+            } else if ((k & 3) == 0) {                            // the next byte down lies in the word below
+                w = wn;
+                if (k >= 8 && k - 4 > lo) wn = *reinterpret_cast<const uint32_t *>(bytes + k - 8);
+            }
+        }
+    }
+    if (owned && !decided && ord >= kStageLines) emit(ord, kNone, kNone);                  // my last line, undecided to its end
+    // ---- 5. write my wave's lines: ordinals lo..hi start in this chunk
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the staging stores of every lane of this wave are done
+    const bool ends_on_nl = bytes[cend - 1] == '\n';
+    const uint32_t lo = chunk_fresh ? 0u : 1u;
+    int64_t hi = ends_on_nl ? (int64_t)total_nl - 1 : (int64_t)total_nl;
+    if (hi >= (int64_t)kStageLines) hi = (int64_t)kStageLines - 1;
+    for (int64_t j = lo + lane; j <= hi; j += 64) {
+        match_start[base_line + (uint64_t)j] = st_s[j];
+        match_end[base_line + (uint64_t)j] = st_e[j];
+    }
+    // the staging array back to "none" for the wave's next chunk (only ordinals <= total_nl were touched)
+    const uint32_t used = total_nl + 1 < kStageLines ? total_nl + 1 : kStageLines;
+    for (uint32_t j = lane; j < used; j += 64) { st_s[j] = kNone; st_e[j] = kNone; }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+}
+
+}  // namespace
+
+size_t search_chunk_bytes() { return kSearchChunk; }
+static size_t search_table_bytes(const SearchChunkDevice &p) { return ((size_t)p.nrows * p.stride + (p.nr * p.ncls + 1) / 2 + 128 + 64) * 4; }
+// staged lines per wave: what the tables leave of the budget (two workgroups per CU), a multiple of 64, 128 at least
+static uint32_t search_stage_lines(const SearchChunkDevice &p) {
+    const size_t tb = search_table_bytes(p);
+    if (tb + (size_t)kSearchWaves * 8 * 128 > kSearchChunkLdsBudget) return 0;
+    size_t n = (kSearchChunkLdsBudget - tb) / ((size_t)kSearchWaves * 8);
+    n = n / 64 * 64;
+    return (uint32_t)(n > kMaxStageLines ? kMaxStageLines : n);
+}
+size_t search_chunks_lds_bytes(const SearchChunkDevice &p) {
+    const uint32_t n = search_stage_lines(p);
+    return n ? search_table_bytes(p) + (size_t)kSearchWaves * 8 * n : (size_t)kSearchChunkLdsBudget + 1;
+}
+int search_chunks(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
+                  uint32_t *match_start, uint32_t *match_end, void *stream) {
+    if (!nchunks) return 0;
+    const size_t lds = search_chunks_lds_bytes(p);
+    if (lds > kSearchChunkLdsBudget) return (int)hipErrorInvalidValue;
+    static LdsAttr attr;
+    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(search_chunks_kernel), lds);
+    if (e != hipSuccess) return (int)e;
+    // persistent workgroups: the tables are loaded once per workgroup, its waves take chunk after chunk
+    size_t blocks = (nchunks + kSearchWaves - 1) / kSearchWaves;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(search_chunks_kernel, dim3((unsigned)blocks), dim3(kSearchWaves * 64), lds, (hipStream_t)stream, p,
+                       bytes, nbytes, chunk_base, nchunks, match_start, match_end, search_stage_lines(p));
+    return (int)hipGetLastError();
+}
+
+}  // namespace dev
+}  // namespace rrx

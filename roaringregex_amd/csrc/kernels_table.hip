@@ -390,31 +390,49 @@ __global__ __launch_bounds__(kThreads) void match_stripes2_onepass_kernel(Dfa2De
 }
 
 // One-pass mode, last step: lane = stripe.  The stream of stripe g (counts[g] results, the first of them dropped if the
-// stripe starts inside a line) goes to bits [base, base + n) of the accept bitmap, base = '\n' before the stripe.
+// stripe starts inside a line) goes to bits [base, base + n) of the accept bitmap, base = '\n' before the stripe.  The
+// streams of a workgroup's 256 stripes cover one contiguous bit range: they are merged in an LDS window first and leave as
+// whole words, consecutive lanes writing consecutive words (atomics only because the first and the last word are shared
+// with the neighbouring workgroups; words beyond the window go to memory directly).
+constexpr uint32_t kCompactWindowWords = 8192;
 __global__ __launch_bounds__(256) void compact_streams_kernel(const uint32_t *__restrict__ counts, const uint64_t *__restrict__ stripe_base,
                                                                size_t nstripes, uint32_t stripe, const uint32_t *__restrict__ slabs,
                                                                uint32_t *__restrict__ accept_bits, size_t cap_words,
                                                                uint32_t *__restrict__ overflow) {
-    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (g >= nstripes) return;
-    const uint32_t c = counts[g];
-    const uint32_t n = (c & kCountMask) + ((c & kExtraResult) ? 1u : 0u);
-    if (!n) return;
-    const uint64_t b = stripe_base[g];
-    const uint64_t base = line_of(b);
-    const bool fresh = (b & kFreshStripe) != 0;
-    const uint32_t *src = slabs + (g / kThreads) * slab_words_per_lane(stripe) * kThreads + (g % kThreads);
-    for (uint32_t k = 0; k * 32 < n; k++) {
-        uint32_t v = src[(size_t)k * kThreads];
-        if (n - k * 32 < 32) v &= (1u << (n - k * 32)) - 1u;
-        if (k == 0 && !fresh) v &= ~1u;                          // that line belongs to the lane before me
-        if (!v) continue;
-        const uint64_t bit = base + (uint64_t)k * 32;
-        const uint64_t word = bit >> 5;
-        const uint32_t sh = (uint32_t)bit & 31u;
-        if (word + (sh ? 1 : 0) >= cap_words) { atomicOr(overflow, 1u); continue; }
-        atomicOr(&accept_bits[word], v << sh);
-        if (sh && (v >> (32u - sh))) atomicOr(&accept_bits[word + 1], v >> (32u - sh));
+    __shared__ uint32_t window[kCompactWindowWords];
+    for (uint32_t i = threadIdx.x; i < kCompactWindowWords; i += 256) window[i] = 0;
+    const size_t g0 = (size_t)blockIdx.x * 256;
+    const uint64_t window_word = line_of(stripe_base[g0]) >> 5;          // g0 < nstripes: the grid is sized that way
+    __syncthreads();
+    const size_t g = g0 + threadIdx.x;
+    if (g < nstripes) {
+        const uint32_t c = counts[g];
+        const uint32_t n = (c & kCountMask) + ((c & kExtraResult) ? 1u : 0u);
+        const uint64_t b = stripe_base[g];
+        const uint64_t base = line_of(b);
+        const bool fresh = (b & kFreshStripe) != 0;
+        const uint32_t *src = slabs + (g / kThreads) * slab_words_per_lane(stripe) * kThreads + (g % kThreads);
+        auto put = [&](uint64_t word, uint32_t v) {
+            if (!v) return;
+            if (word >= cap_words) { atomicOr(overflow, 1u); return; }
+            const uint64_t rel = word - window_word;
+            if (rel < kCompactWindowWords) atomicOr(&window[(uint32_t)rel], v);
+            else atomicOr(&accept_bits[word], v);
+        };
+        for (uint32_t k = 0; k * 32 < n; k++) {
+            uint32_t v = src[(size_t)k * kThreads];
+            if (n - k * 32 < 32) v &= (1u << (n - k * 32)) - 1u;
+            if (k == 0 && !fresh) v &= ~1u;                          // that line belongs to the lane before me
+            const uint64_t bit = base + (uint64_t)k * 32;
+            const uint32_t sh = (uint32_t)bit & 31u;
+            put(bit >> 5, v << sh);
+            if (sh) put((bit >> 5) + 1, v >> (32u - sh));
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < kCompactWindowWords; i += 256) {
+        const uint32_t v = window[i];
+        if (v) atomicOr(&accept_bits[window_word + i], v);
     }
 }
 

@@ -106,4 +106,15 @@ bool lower_dfa(const Reduced &r, uint32_t max_states, DfaProgram &out);
 // right to left - walked backwards from a match end it is accepting exactly at the positions where a match starts.
 bool search_dfas(const Reduced &r, uint32_t max_states, DfaProgram &fwd, DfaProgram &rev);
 
+// Line-mode search table (stripe-wise search kernel): rows = reachable pairs (anchored state, sticky forward state) + the
+// SKIP row, columns = byte classes + '\n'.  Entry = next row | flags: kSearchNewline (the byte was '\n': next row = start),
+// kSearchHit (the byte completes the line's first match: next row = SKIP), kSearchAnchored (with kSearchHit: the line's
+// prefix up to here is itself accepted, i.e. the match with the smallest start begins at the line start).
+constexpr uint32_t kSearchNewline = 1u << 16, kSearchHit = 1u << 17, kSearchAnchored = 1u << 18;
+struct SearchLineProgram {
+    uint32_t nrows = 0, ncols = 0, start = 0, skip = 0;
+    std::vector<uint32_t> table;            // [nrows][ncols]
+};
+bool lower_search_line(const DfaProgram &fwd, const DfaProgram &anchored, uint32_t max_rows, SearchLineProgram &out);
+
 }  // namespace rrx

@@ -149,3 +149,38 @@ class SearchReplay:
             out.append((s, e))
             p = e if e > s else e + 1
         return out
+
+
+class SearchLineReplay:
+    """The stripe-wise search kernel's forward table (rrx_program_words kind 9): [nrows, ncols, start, skip, column[256],
+    entry[nrows][ncols]], entry = next row | '\\n' << 16 | hit << 17 | anchored << 18.  Replayed per line as
+    search_chunks_kernel runs it: step until the hit; an anchored hit starts at the line start, any other walks the
+    reverse table back (SearchReplay's second half)."""
+
+    def __init__(self, line_words, rev_words):
+        w = np.asarray(line_words, dtype=np.int64)
+        self.nrows, self.ncols, self.start, self.skip = int(w[0]), int(w[1]), int(w[2]), int(w[3])
+        self.col = w[4:260]
+        self.T = w[260:].reshape(self.nrows, self.ncols)
+        self.r = DfaReplay(rev_words)
+
+    def search(self, line):
+        row = self.start
+        for i, c in enumerate(line):
+            e = int(self.T[row, self.col[c]])
+            row = e & 0xffff
+            assert not (e >> 16) & 1, "a line holds no newline"
+            if (e >> 17) & 1:
+                assert row == self.skip
+                end = i + 1
+                if (e >> 18) & 1:
+                    return 0, end
+                s, st = end, self.r.start
+                for k in range(end - 1, -1, -1):
+                    st = int(self.r.next[st, self.r.cls[line[k]]])
+                    if st == 0:
+                        break
+                    if self.r.acc[st]:
+                        s = k
+                return s, end
+        return -1, -1

@@ -301,7 +301,7 @@ def test_search_tables_find_the_earliest_ending_leftmost_match():
     """Search has no counterpart in the reference's code; it is pinned to the reference's ACCEPTANCE:
     the oracle tries every substring with whole-string acceptance (smallest end, then smallest start).  The forward
     and reverse tables are replayed on the CPU exactly as the device kernel runs them."""
-    from program_replay import SearchReplay
+    from program_replay import SearchLineReplay, SearchReplay
     rng = random.Random(31)
     pats = ["ab+c", "a*", "(a|b)*abb", "[0-9]+\\.[0-9]+", "x?y?z?", "k(1|10|100)", "a{2,4}b", ".*c", "c.*", "(ab|b)a?", "[^a]b", EMAIL, U2]
     done = 0
@@ -325,8 +325,13 @@ def test_search_tables_find_the_earliest_ending_leftmost_match():
             lines += [b"see http://a.b/c ok", b"xxftp://h.io", b"https://"]
         lines += [b"\x80ab" + lines[0], lines[1] + b"\xc3\xa9" + lines[2]]          # bytes outside the domain are ordinary text
         st, en = o.search_lines(b"\n".join(lines) + b"\n")
+        lw = r.program(rr.PROGRAM_SEARCH_LINE)               # the stripe-wise kernel's table (absent for patterns that accept "")
+        line_rep = SearchLineReplay(lw, rv) if lw is not None else None
+        assert (line_rep is None) == o.accepts(""), p
         for ln, s, e in zip(lines, st, en):
             assert rep.search(ln) == (int(s), int(e)), (p[:50], ln, (int(s), int(e)))
+            if line_rep is not None:
+                assert line_rep.search(ln) == (int(s), int(e)), (p[:50], ln, (int(s), int(e)), "line form")
         cnt, ast, aen = o.search_all(b"\n".join(lines) + b"\n")
         k = 0
         for ln, c in zip(lines, cnt):
