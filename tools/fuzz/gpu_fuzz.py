@@ -24,7 +24,8 @@ while done < npat:
     if o.states_n > 400:
         continue
     engines = []
-    for e in (rr.ENGINE_NFA, rr.ENGINE_DFA, rr.ENGINE_DFA2, rr.ENGINE_DFA_GLOBAL):
+    coop = (rr.ENGINE_NFA_WAVE, rr.ENGINE_NFA_BLOCK) if done % 4 == 1 else ()      # the cooperative engines: every 4th pattern
+    for e in (rr.ENGINE_NFA, rr.ENGINE_DFA, rr.ENGINE_DFA2, rr.ENGINE_DFA_GLOBAL) + coop:
         try:
             engines.append(rr.RRegex(p, e))
         except rr.RRegexError:
@@ -36,6 +37,8 @@ while done < npat:
     total = 0
     seven_bit = done % 2 == 0
     target = big if big else rng.choice([3000, 40000, 300000])
+    if coop:
+        target = min(target, 40000)
     while total < target:
         if mix == "short": n = rng.choice([0, 1, 2, 3, 5, 8])
         elif mix == "empty-heavy": n = rng.choice([0, 0, 0, 1, 4])
@@ -62,6 +65,32 @@ while done < npat:
             bad = np.nonzero(got != want)[0]
             if bad.size:
                 print("MISMATCH", repr(p), r_.engine_name, "stripe", stripe, "mix", mix, "line", int(bad[0]), "of", len(want), flush=True)
+                sys.exit(1)
+            checked += 1
+    # the one-shot entry (no index: one pass over the text with the lane engines), every engine
+    for r_ in engines:
+        bits, nlines = r_.match_device_bits(dev)
+        assert nlines == len(want), (p, r_.engine_name, nlines, len(want))
+        w = bits.cpu().numpy().view(np.uint32)
+        got = ((w[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).astype(np.uint8).reshape(-1)[:nlines]
+        bad = np.nonzero(got != want)[0]
+        if bad.size:
+            print("MISMATCH one-shot", repr(p), r_.engine_name, "mix", mix, "line", int(bad[0]), "of", len(want), flush=True)
+            sys.exit(1)
+        checked += 1
+    # search: first match per line against the oracle's brute force (short lines only: it is cubic)
+    if mix in ("short", "empty-heavy") and len(arr) and len(arr) <= 50000:
+        try:
+            gs, ge = engines[0].search_corpus(rr.Corpus(dev))
+        except rr.RRegexError as err:
+            assert "too large" in str(err)
+            gs = None
+        if gs is not None:
+            st, en = o.search_lines(data)
+            gs, ge = gs.cpu().numpy(), ge.cpu().numpy()
+            bad = np.nonzero((gs != st) | (ge != en))[0]
+            if bad.size:
+                print("MISMATCH search", repr(p), "mix", mix, "line", int(bad[0]), (int(gs[bad[0]]), int(ge[bad[0]])), "want", (int(st[bad[0]]), int(en[bad[0]])), flush=True)
                 sys.exit(1)
             checked += 1
     done += 1
