@@ -127,6 +127,15 @@ public:
         auto *f = static_cast<DeviceIterFactory *>(iter_factory.get());
         if (rrx_match_corpus(f->handle(), corpus, d_accept_bits, stream) != RRX_OK) throw std::runtime_error(rrx_last_error());
     }
+    // the same for a device buffer that has no rrx_corpus yet: ONE pass over the text (no index pass); returns the number
+    // of strings; d_accept_bits holds cap_words words.  Synchronous.
+    size_t match_device(const void *d_bytes, size_t nbytes, uint32_t *d_accept_bits, size_t cap_words, void *stream = nullptr) {
+        auto *f = static_cast<DeviceIterFactory *>(iter_factory.get());
+        size_t nlines = 0;
+        if (rrx_match_device(f->handle(), f->device(), d_bytes, nbytes, d_accept_bits, cap_words, &nlines, stream) != RRX_OK)
+            throw std::runtime_error(rrx_last_error());
+        return nlines;
+    }
     // search: per string the accepted substring [d_start[i], d_end[i]) with the smallest end, then the smallest start
     // (offsets relative to the string; 0xFFFFFFFF = none).  The reference's README promises this, its code has not got it.
     void search_corpus(const rrx_corpus *corpus, uint32_t *d_start, uint32_t *d_end, void *stream = nullptr) {
