@@ -140,7 +140,7 @@ struct rrx_regex {
         // The stripe-wise form (lower_search_line): row indices become byte offsets, flags move to byte 2 of the entry:
         // bit 0 = '\n', bit 1 = hit, and for a hit bit 0 = anchored (flag values 1 = '\n', 2 = hit, 3 = hit, match starts
         // at the line start).
-        size_t oTL = 0, oC4 = 0, oRV = 0;
+        size_t oTL = 0, oTA = 0, oC4 = 0, oRV = 0;
         const uint32_t K = search_fwd.ncls, NR = search_rev.nstates;
         const bool line_form = search_line.nrows && (size_t)search_line.nrows * search_line.ncols * 4 <= 65535 - 512 && K < 128;
         if (line_form) {
@@ -156,7 +156,11 @@ struct rrx_regex {
             c4['\n'] = (uint16_t)(K * 4);
             std::vector<uint16_t> rv(((size_t)NR * K + 1) & ~(size_t)1, 0);
             for (size_t i = 0; i < (size_t)NR * K; i++) { const uint16_t nx = search_rev.next[i]; rv[i] = (uint16_t)(nx | (search_rev.accepting[nx] ? 0x8000u : 0u)); }
+            // "restart" form for all matches: a hit leads back to the start row, the search goes on right behind the match
+            std::vector<uint32_t> TA(T);
+            for (size_t i = 0; i < TA.size(); i++) if ((TA[i] >> 16) & 2u) TA[i] = (TA[i] & 0xffff0000u) | (search_line.start * row_bytes);
             oTL = put(T.data(), T.size() * 4);
+            oTA = put(TA.data(), TA.size() * 4);
             oC4 = put(c4, sizeof c4);
             oRV = put(rv.data(), rv.size() * 2);
             t.chunk.nrows = search_line.nrows; t.chunk.stride = search_line.ncols;
@@ -174,6 +178,7 @@ struct rrx_regex {
         t.dev.acc_f = base + oAF; t.dev.acc_r = base + oAR;
         if (line_form) {
             t.chunk.T = reinterpret_cast<const uint32_t *>(base + oTL);
+            t.chunk.T_all = reinterpret_cast<const uint32_t *>(base + oTA);
             t.chunk.cls4 = reinterpret_cast<const uint16_t *>(base + oC4);
             t.chunk.rev = reinterpret_cast<const uint16_t *>(base + oRV);
             t.chunk.cls = base + oC;
@@ -738,6 +743,13 @@ int rrx_search_all_count(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_c
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
     if (!c->nlines) return RRX_OK;
+    if (const dev::SearchChunkDevice *ct = re->search_chunk_tables(c->device)) {     // stripe-wise
+        rc = chunk_index(c, stream);
+        if (rc) return rc;
+        int e = dev::search_chunks_count(*ct, c->d_bytes, c->nbytes, c->d_chunk_base, c->nchunks, d_count, stream);
+        if (e) return hip_fail((hipError_t)e, "search_chunks_count launch");
+        return RRX_OK;
+    }
     rc = line_offsets(c, stream);
     if (rc) return rc;
     int e = dev::search_all(*t, c->d_bytes, c->nbytes, c->d_line_off, c->nlines, d_count, nullptr, nullptr, nullptr, stream);
@@ -752,6 +764,13 @@ int rrx_search_all_fill(const rrx_regex *re, const rrx_corpus *c, const uint64_t
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
     if (!c->nlines) return RRX_OK;
+    if (const dev::SearchChunkDevice *ct = re->search_chunk_tables(c->device)) {     // stripe-wise
+        rc = chunk_index(c, stream);
+        if (rc) return rc;
+        int e = dev::search_chunks_fill(*ct, c->d_bytes, c->nbytes, c->d_chunk_base, c->nchunks, d_first, d_start, d_end, stream);
+        if (e) return hip_fail((hipError_t)e, "search_chunks_fill launch");
+        return RRX_OK;
+    }
     rc = line_offsets(c, stream);
     if (rc) return rc;
     int e = dev::search_all(*t, c->d_bytes, c->nbytes, c->d_line_off, c->nlines, nullptr, d_first, d_start, d_end, stream);

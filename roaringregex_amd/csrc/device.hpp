@@ -171,6 +171,7 @@ struct SearchChunkDevice {
     uint32_t nrows = 0, stride = 0, start_off = 0, skip_off = 0;
     uint32_t nr = 0, ncls = 0, start_r = 0;
     const uint32_t *T = nullptr;                 // [nrows][stride]
+    const uint32_t *T_all = nullptr;             // the same with every hit leading back to the start row (all matches)
     const uint16_t *cls4 = nullptr;              // [256] byte -> 4 * column
     const uint16_t *rev = nullptr;               // [nr][ncls] reverse table, bit 15 = leads to an accepting state
     const uint8_t *cls = nullptr;                // [256] byte -> class
@@ -181,6 +182,11 @@ size_t search_chunks_lds_bytes(const SearchChunkDevice &p);
 // chunk_base: per-chunk newline prefix in the stripe_base format (bit 63: the chunk begins at the start of a line)
 int search_chunks(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
                   uint32_t *match_start, uint32_t *match_end, void *stream);
+// all matches: count[line], then (with the caller's exclusive prefix `first`) the matches of line i at first[i], first[i] + 1, ...
+int search_chunks_count(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
+                        uint32_t *count, void *stream);
+int search_chunks_fill(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
+                       const uint64_t *first, uint32_t *match_start, uint32_t *match_end, void *stream);
 size_t search_lds_bytes(const SearchDevice &p);
 // line_off[i] = offset of the first byte of line i (built once per corpus from the stripe index); nlines + 1 entries are
 // the caller's to size, entry nlines is written only when the corpus ends in '\n'.

@@ -15,6 +15,10 @@
 //   4. a lane whose last line is still undecided at the end of its sub-stripe follows it into the next lanes' bytes;
 //   5. the wave writes its lines' results, consecutive lanes consecutive lines: whole sectors, where one lane per stripe
 //      appending 8 bytes per line left them as partial writes (10 ms for the line offsets alone in the first version).
+// ALL matches of every line (rrx_search_all_count / _fill) run the same kernel in two more modes with the "restart" form
+// of the table (a hit leads back to the start row instead of SKIP: the search goes on right after the match): kCount
+// counts the hits per line; kFill numbers a line's matches from first[line] (the caller's exclusive prefix of the counts),
+// bounds every walk back by the end of the previous match, and stages the wave's matches - a contiguous range of slots.
 #include "kernels_common.hpp"
 
 namespace rrx {
@@ -57,8 +61,15 @@ __device__ __forceinline__ size_t reverse_walk(const SearchLds &t, const uint8_t
     return best;
 }
 
+enum { kFirst = 0, kCount = 1, kFill = 2 };
+
+// MODE kFirst: match_start/match_end[line] = first match of the line (kNone: no match).
+// MODE kCount: match_start[line] = number of matches of the line (match_end unused).
+// MODE kFill : match_start/match_end[first[line] + k] = k-th match of the line.
+template <int MODE>
 __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void search_chunks_kernel(SearchChunkDevice prog, const uint8_t *__restrict__ bytes, size_t nbytes,
                                                                           const uint64_t *__restrict__ chunk_base, size_t nchunks,
+                                                                          const uint64_t *__restrict__ first,
                                                                           uint32_t *__restrict__ match_start, uint32_t *__restrict__ match_end,
                                                                           uint32_t kStageLines) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -70,14 +81,17 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     uint32_t *T = C4 + 128;
     uint32_t *R = T + t_words;
     uint32_t *C = R + rev_words;                                  // 64 words
-    uint32_t *stage = C + 64;                                     // [wave][2][kStageLines]
+    uint32_t *stage = C + 64;                                     // [wave][kArrays][kStageLines]
+    constexpr uint32_t kArrays = MODE == kFirst ? 2 : MODE == kCount ? 1 : 3;
+    constexpr uint32_t kStageInit = MODE == kCount ? 0u : kNone;  // a line without a match: "none" / zero matches
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem != 0u) __builtin_trap();
     const uint32_t t_base = 512u;                                 // LDS address of T
-    for (uint32_t i = threadIdx.x; i < t_words; i += blockDim.x) T[i] = prog.T[i] + t_base;
+    const uint32_t *Tsrc = MODE == kFirst ? prog.T : prog.T_all;
+    for (uint32_t i = threadIdx.x; i < t_words; i += blockDim.x) T[i] = Tsrc[i] + t_base;
     for (uint32_t i = threadIdx.x; i < rev_words; i += blockDim.x) R[i] = reinterpret_cast<const uint32_t *>(prog.rev)[i];
     for (uint32_t i = threadIdx.x; i < 128; i += blockDim.x) C4[i] = reinterpret_cast<const uint32_t *>(prog.cls4)[i];
     for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x) C[i] = reinterpret_cast<const uint32_t *>(prog.cls)[i];
-    for (uint32_t i = threadIdx.x; i < kSearchWaves * 2 * kStageLines; i += blockDim.x) stage[i] = kNone;
+    for (uint32_t i = threadIdx.x; i < kSearchWaves * kArrays * kStageLines; i += blockDim.x) stage[i] = kStageInit;
     __syncthreads();
     SearchLds t;
     t.T = smem; t.rev = reinterpret_cast<const uint16_t *>(R); t.cls4 = reinterpret_cast<const uint16_t *>(C4);
@@ -85,7 +99,8 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     t.start_off = prog.start_off + t_base; t.skip_off = prog.skip_off + t_base;
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t *st_s = stage + (size_t)wave * 2 * kStageLines, *st_e = st_s + kStageLines;
+    uint32_t *st_s = stage + (size_t)wave * kArrays * kStageLines, *st_e = st_s + kStageLines;
+    uint32_t *st_f = st_e + kStageLines;                          // kFill: first[line] - first[the wave's first line]
     for (size_t chunk = (size_t)blockIdx.x * kSearchWaves + wave; chunk < nchunks; chunk += (size_t)gridDim.x * kSearchWaves) {
     const size_t cstart = chunk * (size_t)kSearchChunk;
     const size_t cend = cstart + kSearchChunk < nbytes ? cstart + kSearchChunk : nbytes;      // end of the chunk's data
@@ -175,125 +190,151 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     const uint32_t total_nl = __shfl(incl, 63, 64);
     uint32_t ord = incl - nl;                                     // ordinal (within the chunk) of the line my first byte is in
 
-    // ---- 3. my last line is still being searched at the end of my bytes (the row is not SKIP, the line did not end
-    // there): follow it into the next lanes' bytes until it is decided
-    size_t tail_end = 0;                                          // end of a match found that way
-    uint32_t tail_flags = 0;
-    if (vlen == kSearchS && (e & 0xffffu) != t.skip_off && last_byte != '\n' && (fresh || nl)) {
-        size_t pos = my_end;                                      // a multiple of 4
-        bool ended = false;
-        // sixteen bytes per load, the next sixteen requested before these are stepped (the loop is a chain of memory
-        // round trips otherwise: measured 40 % of the kernel); stepped like the forward pass, a text word at a time, the
-        // first event decides
-        uint4 cur = make_uint4(0, 0, 0, 0), nxt = cur;
-        if (pos + 16 <= nbytes) cur = *reinterpret_cast<const uint4 *>(bytes + pos);
-        while (pos + 16 <= nbytes && !ended) {
-            if (pos + 32 <= nbytes) nxt = *reinterpret_cast<const uint4 *>(bytes + pos + 16);
-            const uint32_t ww[4] = {cur.x, cur.y, cur.z, cur.w};
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                if (!ended) {
-                    const uint32_t w = ww[q];
-                    uint32_t acc = 0, a0, a1, a2, a3, c0, c1, c2, c3;
-#define RRX_SEARCH_COL(W, SEL, A, C)                                                                                              \
-                    asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL : "=v"(A) : "v"(1u), "v"(W)); \
-                    C = *reinterpret_cast<lds_u16_ptr>(A);
-#define RRX_SEARCH_STEP(C)                                                                                                        \
-                    {                                                                                                             \
-                        uint32_t a_;                                                                                              \
-                        asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(a_) : "v"(e), "v"(C)); \
-                        e = *reinterpret_cast<lds_u32_ptr>(a_);                                                                  \
-                        acc <<= 2;                                                                                                \
-                        asm volatile("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(acc) : "v"(e), "v"(acc)); \
-                    }
-                    RRX_SEARCH_COL(w, "BYTE_0", a0, c0) RRX_SEARCH_COL(w, "BYTE_1", a1, c1) RRX_SEARCH_COL(w, "BYTE_2", a2, c2) RRX_SEARCH_COL(w, "BYTE_3", a3, c3)
-                    RRX_SEARCH_STEP(c0) RRX_SEARCH_STEP(c1) RRX_SEARCH_STEP(c2) RRX_SEARCH_STEP(c3)
-#undef RRX_SEARCH_STEP
-#undef RRX_SEARCH_COL
-                    if (acc) {                                    // 2 bits per byte, byte 0 in bits 7..6
-                        const int z = (__clz((int)acc) - 24) >> 1;                // first byte with an event
-                        const uint32_t f = (acc >> (6 - 2 * z)) & 3u;
-                        if (f & 2u) { tail_end = pos + (size_t)(4 * q + z) + 1; tail_flags = f; }
-                        ended = true;                             // a hit, or the line's '\n'
-                    }
-                }
-            }
-            pos += 16;
-            cur = nxt;
-        }
-        for (; pos < nbytes && !ended; pos++) {                   // the last bytes of the corpus
-            const uint32_t f = step(e, bytes[pos]);
-            if (f & 2u) { tail_end = pos + 1; tail_flags = f; }
-            if (f) ended = true;
+    // ---- 3. results.  kFirst / kCount: staged by line ordinal.  kFill: the wave's matches are the slots first[its first
+    // line] ... in line order; the slot base of every staged line comes from `first`, relative to the wave's first slot.
+    const bool ends_on_nl = bytes[cend - 1] == '\n';
+    const uint32_t lo_ord = chunk_fresh ? 0u : 1u;                // ordinals lo..hi start in this chunk: they are the wave's
+    const int64_t hi_ord = ends_on_nl ? (int64_t)total_nl - 1 : (int64_t)total_nl;
+    uint64_t F0 = 0;                                              // kFill: first slot of the wave
+    if constexpr (MODE == kFill) {
+        if ((int64_t)lo_ord <= hi_ord) {
+            F0 = first[base_line + lo_ord];
+            for (int64_t j = lo_ord + lane; j <= hi_ord && j < (int64_t)kStageLines; j += 64) st_f[j] = (uint32_t)(first[base_line + (uint64_t)j] - F0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         }
     }
-    // ---- 4. replay the events in byte order (one loop body: the words rotate through ev[0]); the match found by
-    // following comes last.  A hit whose start is not known QUEUES a job (line start, match end, line number): walking
-    // back right here would make the lanes of a wave take turns, each waiting through the others' walks (measured: 33 ms
-    // for 8 GiB).  Positions are 32-bit offsets from the chunk start from here on.
-    auto emit = [&](uint32_t line_ord, uint32_t s_rel, uint32_t e_rel) {
-        if (line_ord < kStageLines) { st_s[line_ord] = s_rel; st_e[line_ord] = e_rel; }
-        else { match_start[base_line + line_ord] = s_rel; match_end[base_line + line_ord] = e_rel; }
+    auto slot_base = [&](uint32_t line_ord) -> uint32_t {         // kFill: first slot of a line, relative to F0
+        return line_ord < kStageLines ? st_f[line_ord] : (uint32_t)(first[base_line + line_ord] - F0);
     };
+    // kFirst: (line ordinal, start, end); kCount: (line ordinal, count, -); kFill: (slot relative to F0, start, end)
+    auto emit = [&](uint32_t idx, uint32_t v0, uint32_t v1) {
+        if (idx < kStageLines) { st_s[idx] = v0; if (MODE != kCount) st_e[idx] = v1; }
+        else {
+            const uint64_t at = (MODE == kFill ? F0 : base_line) + idx;
+            match_start[at] = v0;
+            if (MODE != kCount) match_end[at] = v1;
+        }
+    };
+    // ---- 4. the events in byte order, then the rest of my last line beyond my bytes, then nothing: one loop so that the
+    // queue of walk-back jobs is drained by ONE copy of the walk.  A hit whose start is not known QUEUES a job (lower
+    // bound, match end, where to put the result, line start): walking back right at the hit would make the lanes of a
+    // wave take turns, each waiting through the others' walks (measured: 33 ms for 8 GiB).  Positions are 32-bit
+    // offsets from the chunk start from here on.
     constexpr int kJobs = 4;
-    uint32_t job_ls[kJobs], job_e[kJobs], job_ord[kJobs];         // slot 0 is the next to run
+    uint32_t job_lo[kJobs], job_e[kJobs], job_at[kJobs], job_ls[kJobs];       // slot 0 is the next to run
     uint32_t njobs = 0;
-    bool owned = fresh, decided = false;                          // the current line: is it mine, has its match been found
+    bool owned = fresh, decided = false;                          // the current line: is it mine; kFirst: has its match been found
     const uint32_t my_rel = (uint32_t)(my - cstart), my_end_rel = (uint32_t)(my_end - cstart);
     uint32_t ls = my_rel;                                         // its first byte (valid if owned)
-    uint32_t tail_rel = tail_end ? (uint32_t)(tail_end - cstart) : 0u;
+    uint32_t lb = my_rel;                                         // kFill: a match may not start before here (the previous match's end)
+    uint32_t cnt = 0;                                             // kCount / kFill: matches of the current line so far
+    uint32_t emitted = 0;                                         // kFill: matches of lines that are mine
+    auto on_hit = [&](uint32_t pos, uint32_t f) {                 // the byte at `pos` completes a match
+        if (!owned) return;
+        if constexpr (MODE == kCount) { cnt++; return; }
+        const uint32_t at = MODE == kFirst ? ord : slot_base(ord) + cnt;
+        const uint32_t lower = MODE == kFirst ? ls : lb;
+        if (f == 3u) emit(at, lower - ls, pos + 1 - ls);          // accepted from the restart point itself: it starts there
+        else if (njobs < kJobs) {
+#pragma unroll
+            for (int j = 0; j < kJobs; j++)
+                if ((uint32_t)j == njobs) { job_lo[j] = lower; job_e[j] = pos + 1; job_at[j] = at; job_ls[j] = ls; }
+            njobs++;
+        } else {                                                  // (several matches inside one text word with the queue full)
+            const size_t s0 = reverse_walk(t, bytes, cstart + lower, cstart + pos + 1);
+            emit(at, (uint32_t)(s0 - cstart) - ls, pos + 1 - ls);
+        }
+        if constexpr (MODE == kFirst) decided = true;
+        else { cnt++; emitted++; lb = pos + 1; }
+    };
+    auto on_newline = [&](uint32_t pos) {
+        if constexpr (MODE == kFirst) { if (owned && !decided && ord >= kStageLines) emit(ord, kNone, kNone); }      // (staged lines default to "none")
+        if constexpr (MODE == kCount) { if (owned) emit(ord, cnt, 0u); }
+        ord++;
+        ls = pos + 1; lb = ls; cnt = 0;
+        owned = ls < my_end_rel;                                  // a line that starts at my_end is the next lane's
+        decided = false;
+    };
     uint32_t word_pos = my_rel;                                   // position of byte 0 of ev[0]
     int words_left = kEv;
-    bool events_left = true;
-    while (events_left || njobs) {
-        // ---- 4a. events, until they run out or the job queue is full
-        while (events_left && njobs < kJobs) {
-            uint32_t f, pos;
+    int phase = 0;                                                // 0: my events, 1: following my last line, 2: done
+    size_t fbyte = my_end;                                        // follow position (word by word while whole 16-byte blocks lie in the data)
+    uint4 cur = make_uint4(0, 0, 0, 0), nxt = cur;
+    while (phase < 2 || njobs) {
+        // ---- 4a. my events, until they run out or the job queue is full
+        while (phase == 0 && njobs < kJobs) {
             if (ev[0]) {
                 const int z = __clz((int)ev[0]) >> 1;             // byte of the word, 0 = first
-                f = (ev[0] >> (30 - 2 * z)) & 3u;
+                const uint32_t f = (ev[0] >> (30 - 2 * z)) & 3u;
                 ev[0] &= ~(3u << (30 - 2 * z));
-                pos = word_pos + (uint32_t)z;
+                if (f == 1u) on_newline(word_pos + (uint32_t)z); else on_hit(word_pos + (uint32_t)z, f);
             } else if (words_left > 1) {
                 words_left--;
                 word_pos += 16;
 #pragma unroll
                 for (int i = 0; i + 1 < kEv; i++) ev[i] = ev[i + 1];
                 ev[kEv - 1] = 0;
-                continue;
-            } else if (tail_rel) {
-                f = tail_flags; pos = tail_rel - 1; tail_rel = 0;
-            } else { events_left = false; break; }
-            if (f == 1u) {                                        // '\n': the next line begins
-                if (owned && !decided && ord >= kStageLines) emit(ord, kNone, kNone);      // (staged lines default to "none")
-                ord++;
-                ls = pos + 1;
-                owned = ls < my_end_rel;                          // a line that starts at my_end is the next lane's
-                decided = false;
-            } else {                                              // the first match of my current line ends after this byte
-                if (owned) {
-                    if (f == 3u) emit(ord, 0u, pos + 1 - ls);     // the prefix itself is accepted: it starts at the line start
-                    else {
-#pragma unroll
-                        for (int j = 0; j < kJobs; j++)
-                            if ((uint32_t)j == njobs) { job_ls[j] = ls; job_e[j] = pos + 1; job_ord[j] = ord; }
-                        njobs++;
-                    }
-                }
-                decided = true;
+            } else {
+                // my last line goes on beyond my bytes and is still open (kFirst: undecided): follow it
+                const bool open_line = vlen == kSearchS && last_byte != '\n' && owned && !(MODE == kFirst && decided);
+                phase = open_line ? 1 : 2;
+                if (open_line && fbyte + 16 <= nbytes) cur = *reinterpret_cast<const uint4 *>(bytes + fbyte);
             }
         }
-        // ---- 4b. walk back from every queued match end to its line start with the reverse table: smallest start.  Every
+        // ---- 4b. the rest of my last line: sixteen bytes per load, the next sixteen requested before these are stepped
+        // (the loop is a chain of memory round trips otherwise), stepped like the forward pass, a text word per turn
+        while (phase == 1 && njobs < kJobs) {
+            const size_t fpos = fbyte & ~(size_t)15;
+            if (fpos + 16 <= nbytes) {
+                const uint32_t fq = (uint32_t)(fbyte & 15) >> 2;  // text word of `cur` to step
+                if (fq == 0 && fpos + 32 <= nbytes) nxt = *reinterpret_cast<const uint4 *>(bytes + fpos + 16);
+                const uint32_t w = fq == 0 ? cur.x : fq == 1 ? cur.y : fq == 2 ? cur.z : cur.w;
+                uint32_t acc = 0, a0, a1, a2, a3, c0, c1, c2, c3;
+#define RRX_SEARCH_COL(W, SEL, A, C)                                                                                              \
+                asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL : "=v"(A) : "v"(1u), "v"(W)); \
+                C = *reinterpret_cast<lds_u16_ptr>(A);
+#define RRX_SEARCH_STEP(C)                                                                                                        \
+                {                                                                                                                 \
+                    uint32_t a_;                                                                                                  \
+                    asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(a_) : "v"(e), "v"(C)); \
+                    e = *reinterpret_cast<lds_u32_ptr>(a_);                                                                      \
+                    acc <<= 2;                                                                                                    \
+                    asm volatile("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(acc) : "v"(e), "v"(acc)); \
+                }
+                RRX_SEARCH_COL(w, "BYTE_0", a0, c0) RRX_SEARCH_COL(w, "BYTE_1", a1, c1) RRX_SEARCH_COL(w, "BYTE_2", a2, c2) RRX_SEARCH_COL(w, "BYTE_3", a3, c3)
+                RRX_SEARCH_STEP(c0) RRX_SEARCH_STEP(c1) RRX_SEARCH_STEP(c2) RRX_SEARCH_STEP(c3)
+#undef RRX_SEARCH_STEP
+#undef RRX_SEARCH_COL
+                const uint32_t wrel = (uint32_t)(fbyte - cstart);
+                while (acc && phase == 1) {                       // 2 bits per byte, byte 0 in bits 7..6
+                    const int z = (__clz((int)acc) - 24) >> 1;
+                    const uint32_t f = (acc >> (6 - 2 * z)) & 3u;
+                    acc &= ~(3u << (6 - 2 * z));
+                    if (f == 1u) phase = 2;                       // the line's '\n': done (what lies behind it is not mine)
+                    else { on_hit(wrel + (uint32_t)z, f); if (MODE == kFirst) phase = 2; }
+                }
+                fbyte += 4;
+                if ((fbyte & 15) == 0) cur = nxt;
+            } else {                                              // the last bytes of the corpus, one by one
+                for (; fbyte < nbytes && phase == 1 && njobs < kJobs; fbyte++) {
+                    const uint32_t f = step(e, bytes[fbyte]);
+                    if (f == 1u) phase = 2;
+                    else if (f) { on_hit((uint32_t)(fbyte - cstart), f); if (MODE == kFirst) phase = 2; }
+                }
+                if (fbyte >= nbytes) phase = 2;                   // the end of the data ends the line
+            }
+        }
+        // ---- 4c. walk back from every queued match end to its lower bound with the reverse table: smallest start.  Every
         // lane runs through its own jobs back to back, one reverse step per turn of the loop (text re-read from L1/L2,
         // four bytes per load, the next word requested one word ahead).
         bool active = false;
         size_t k = 0, lo = 0, best = 0, e_abs = 0;
-        uint32_t r = 0, w = 0, wn = 0, cur_ord = 0;
+        uint32_t r = 0, w = 0, wn = 0, cur_at = 0, cur_ls = 0;
         while (active || njobs) {
             if (!active) {
-                lo = cstart + job_ls[0]; e_abs = cstart + job_e[0]; cur_ord = job_ord[0];
+                lo = cstart + job_lo[0]; e_abs = cstart + job_e[0]; cur_at = job_at[0]; cur_ls = job_ls[0];
 #pragma unroll
-                for (int j = 0; j + 1 < kJobs; j++) { job_ls[j] = job_ls[j + 1]; job_e[j] = job_e[j + 1]; job_ord[j] = job_ord[j + 1]; }
+                for (int j = 0; j + 1 < kJobs; j++) { job_lo[j] = job_lo[j + 1]; job_e[j] = job_e[j + 1]; job_at[j] = job_at[j + 1]; job_ls[j] = job_ls[j + 1]; }
                 njobs--;
                 k = e_abs; best = e_abs; r = t.start_r; active = true;
                 const size_t a0 = (k - 1) & ~(size_t)3;           // e_abs > lo: a match is never empty here
@@ -306,8 +347,8 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
             const uint32_t x = t.rev[r * t.K + t.cls[c]];
             r = x & 0x7fffu;
             if (r && (x & 0x8000u)) best = k;
-            if (!r || k == lo) {                                  // dead, or at the line start: the job is done
-                emit(cur_ord, (uint32_t)(best - lo), (uint32_t)(e_abs - lo));
+            if (!r || k == lo) {                                  // dead, or at the lower bound: the job is done
+                emit(cur_at, (uint32_t)(best - cstart) - cur_ls, (uint32_t)(e_abs - cstart) - cur_ls);
                 active = false;
             } else if ((k & 3) == 0) {                            // the next byte down lies in the word below
                 w = wn;
@@ -315,20 +356,28 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
             }
         }
     }
-    if (owned && !decided && ord >= kStageLines) emit(ord, kNone, kNone);                  // my last line, undecided to its end
-    // ---- 5. write my wave's lines: ordinals lo..hi start in this chunk
+    // my last line, open to the end of the data (or ended by its '\n' beyond my bytes)
+    if constexpr (MODE == kFirst) { if (owned && !decided && ord >= kStageLines) emit(ord, kNone, kNone); }
+    if constexpr (MODE == kCount) { if (owned) emit(ord, cnt, 0u); }
+    // ---- 5. write the wave's results: whole sectors, consecutive lanes consecutive entries
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the staging stores of every lane of this wave are done
-    const bool ends_on_nl = bytes[cend - 1] == '\n';
-    const uint32_t lo = chunk_fresh ? 0u : 1u;
-    int64_t hi = ends_on_nl ? (int64_t)total_nl - 1 : (int64_t)total_nl;
-    if (hi >= (int64_t)kStageLines) hi = (int64_t)kStageLines - 1;
-    for (int64_t j = lo + lane; j <= hi; j += 64) {
-        match_start[base_line + (uint64_t)j] = st_s[j];
-        match_end[base_line + (uint64_t)j] = st_e[j];
+    if constexpr (MODE == kFill) {
+        uint32_t tot = emitted;
+#pragma unroll
+        for (int d = 32; d; d >>= 1) tot += __shfl_xor(tot, d, 64);
+        const uint32_t staged = tot < kStageLines ? tot : kStageLines;
+        for (uint32_t j = lane; j < staged; j += 64) { match_start[F0 + j] = st_s[j]; match_end[F0 + j] = st_e[j]; }
+    } else {
+        int64_t hi = hi_ord;
+        if (hi >= (int64_t)kStageLines) hi = (int64_t)kStageLines - 1;
+        for (int64_t j = lo_ord + lane; j <= hi; j += 64) {
+            match_start[base_line + (uint64_t)j] = st_s[j];
+            if (MODE == kFirst) match_end[base_line + (uint64_t)j] = st_e[j];
+        }
+        // the staging array back to its default for the wave's next chunk (only ordinals <= total_nl were touched)
+        const uint32_t used = total_nl + 1 < kStageLines ? total_nl + 1 : kStageLines;
+        for (uint32_t j = lane; j < used; j += 64) { st_s[j] = kStageInit; if (MODE == kFirst) st_e[j] = kStageInit; }
     }
-    // the staging array back to "none" for the wave's next chunk (only ordinals <= total_nl were touched)
-    const uint32_t used = total_nl + 1 < kStageLines ? total_nl + 1 : kStageLines;
-    for (uint32_t j = lane; j < used; j += 64) { st_s[j] = kNone; st_e[j] = kNone; }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
 }
@@ -337,32 +386,47 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
 
 size_t search_chunk_bytes() { return kSearchChunk; }
 static size_t search_table_bytes(const SearchChunkDevice &p) { return ((size_t)p.nrows * p.stride + (p.nr * p.ncls + 1) / 2 + 128 + 64) * 4; }
-// staged lines per wave: what the tables leave of the budget (two workgroups per CU), a multiple of 64, 128 at least
-static uint32_t search_stage_lines(const SearchChunkDevice &p) {
-    const size_t tb = search_table_bytes(p);
-    if (tb + (size_t)kSearchWaves * 8 * 128 > kSearchChunkLdsBudget) return 0;
-    size_t n = (kSearchChunkLdsBudget - tb) / ((size_t)kSearchWaves * 8);
+// staged entries per wave: what the tables leave of the budget (two workgroups per CU), a multiple of 64, 128 at least
+// (2 arrays for the first match, 1 for the counts, 3 for the fill pass)
+static uint32_t search_stage_lines(const SearchChunkDevice &p, int mode) {
+    const size_t tb = search_table_bytes(p), per = (size_t)kSearchWaves * 4 * (mode == kFirst ? 2 : mode == kCount ? 1 : 3);
+    if (tb + per * 128 > kSearchChunkLdsBudget) return 0;
+    size_t n = (kSearchChunkLdsBudget - tb) / per;
     n = n / 64 * 64;
     return (uint32_t)(n > kMaxStageLines ? kMaxStageLines : n);
 }
-size_t search_chunks_lds_bytes(const SearchChunkDevice &p) {
-    const uint32_t n = search_stage_lines(p);
-    return n ? search_table_bytes(p) + (size_t)kSearchWaves * 8 * n : (size_t)kSearchChunkLdsBudget + 1;
+size_t search_chunks_lds_bytes(const SearchChunkDevice &p) {          // of the most demanding mode (fill)
+    const uint32_t n = search_stage_lines(p, kFill);
+    return n ? search_table_bytes(p) + (size_t)kSearchWaves * 12 * n : (size_t)kSearchChunkLdsBudget + 1;
 }
-int search_chunks(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
-                  uint32_t *match_start, uint32_t *match_end, void *stream) {
+template <int MODE>
+static int launch_search_chunks(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
+                                const uint64_t *first, uint32_t *out0, uint32_t *out1, void *stream) {
     if (!nchunks) return 0;
-    const size_t lds = search_chunks_lds_bytes(p);
-    if (lds > kSearchChunkLdsBudget) return (int)hipErrorInvalidValue;
+    const uint32_t lines = search_stage_lines(p, MODE);
+    if (!lines) return (int)hipErrorInvalidValue;
+    const size_t lds = search_table_bytes(p) + (size_t)kSearchWaves * 4 * (MODE == kFirst ? 2 : MODE == kCount ? 1 : 3) * lines;
     static LdsAttr attr;
-    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(search_chunks_kernel), lds);
+    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(search_chunks_kernel<MODE>), lds);
     if (e != hipSuccess) return (int)e;
     // persistent workgroups: the tables are loaded once per workgroup, its waves take chunk after chunk
     size_t blocks = (nchunks + kSearchWaves - 1) / kSearchWaves;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(search_chunks_kernel, dim3((unsigned)blocks), dim3(kSearchWaves * 64), lds, (hipStream_t)stream, p,
-                       bytes, nbytes, chunk_base, nchunks, match_start, match_end, search_stage_lines(p));
+    hipLaunchKernelGGL(search_chunks_kernel<MODE>, dim3((unsigned)blocks), dim3(kSearchWaves * 64), lds, (hipStream_t)stream, p, bytes, nbytes, chunk_base,
+                       nchunks, first, out0, out1, lines);
     return (int)hipGetLastError();
+}
+int search_chunks(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
+                  uint32_t *match_start, uint32_t *match_end, void *stream) {
+    return launch_search_chunks<kFirst>(p, bytes, nbytes, chunk_base, nchunks, nullptr, match_start, match_end, stream);
+}
+int search_chunks_count(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
+                        uint32_t *count, void *stream) {
+    return launch_search_chunks<kCount>(p, bytes, nbytes, chunk_base, nchunks, nullptr, count, nullptr, stream);
+}
+int search_chunks_fill(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
+                       const uint64_t *first, uint32_t *match_start, uint32_t *match_end, void *stream) {
+    return launch_search_chunks<kFill>(p, bytes, nbytes, chunk_base, nchunks, first, match_start, match_end, stream);
 }
 
 }  // namespace dev
