@@ -1,8 +1,8 @@
 // kernels_search.hip — stripe-wise search (rrx_search_corpus): for every line the accepted substring
 // with the smallest end, then the smallest start.  Shared device code: kernels_common.hpp.
 //
-// Geometry: a WAVE owns a contiguous chunk of 64 * S bytes, lane l its sub-stripe [l*S, (l+1)*S) (S = 128: one cache
-// line per lane, held in registers).  A line belongs to the lane its first byte lies in.  Per lane:
+// Geometry: a WAVE owns a contiguous chunk of 64 * S bytes, lane l its sub-stripe [l*S, (l+1)*S) (S = 256: two cache
+// lines per lane, one after the other in registers).  A line belongs to the lane its first byte lies in.  Per lane:
 //   1. forward pass over its S bytes with the line-mode forward table in LDS ("any bytes, then the pattern"; rows carry
 //      two flags: the byte was '\n' / the byte completed the first match of its line, after which the row is SKIP until
 //      the next '\n'): 2 LDS gathers and 4 VALU per byte, no branch - the flags are shifted into event words, 2 bits per
@@ -26,10 +26,12 @@ namespace dev {
 namespace {
 
 constexpr int kSearchWaves = 8;                 // waves per workgroup (one table copy in LDS serves them)
-constexpr int kSearchS = 128;                   // bytes per lane
+constexpr int kSearchS = 256;                   // bytes per lane: two 128-byte rounds (the per-lane costs that do not scale with
+                                                // the bytes - following the last line, numbering, write-out - are paid half as often)
 constexpr uint32_t kSearchChunk = 64 * kSearchS;
-constexpr uint32_t kMaxStageLines = 1024;       // staged lines per wave (what the tables leave of the LDS budget, at most this); lines beyond go to memory directly
+constexpr uint32_t kMaxStageLines = 2048;       // staged lines per wave (what the tables leave of the LDS budget, at most this); lines beyond go to memory directly
 constexpr uint32_t kNone = 0xffffffffu;
+constexpr uint32_t kDirect = 0xfffffffeu;       // staged entry: the result did not fit 16 + 16 bits and went to memory directly
 
 typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
 typedef const __attribute__((address_space(3))) uint16_t *lds_u16_ptr;
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     uint32_t *R = T + t_words;
     uint32_t *C = R + rev_words;                                  // 64 words
     uint32_t *stage = C + 64;                                     // [wave][kArrays][kStageLines]
-    constexpr uint32_t kArrays = MODE == kFirst ? 2 : MODE == kCount ? 1 : 3;
+    constexpr uint32_t kArrays = MODE == kFill ? 2 : 1;           // results packed start | end << 16 (kCount: the count); kFill: + slot bases
     constexpr uint32_t kStageInit = MODE == kCount ? 0u : kNone;  // a line without a match: "none" / zero matches
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem != 0u) __builtin_trap();
     const uint32_t t_base = 512u;                                 // LDS address of T
@@ -99,8 +101,8 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     t.start_off = prog.start_off + t_base; t.skip_off = prog.skip_off + t_base;
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint32_t *st_s = stage + (size_t)wave * kArrays * kStageLines, *st_e = st_s + kStageLines;
-    uint32_t *st_f = st_e + kStageLines;                          // kFill: first[line] - first[the wave's first line]
+    uint32_t *st_s = stage + (size_t)wave * kArrays * kStageLines;
+    uint32_t *st_f = st_s + kStageLines;                          // kFill: first[line] - first[the wave's first line]
     for (size_t chunk = (size_t)blockIdx.x * kSearchWaves + wave; chunk < nchunks; chunk += (size_t)gridDim.x * kSearchWaves) {
     const size_t cstart = chunk * (size_t)kSearchChunk;
     const size_t cend = cstart + kSearchChunk < nbytes ? cstart + kSearchChunk : nbytes;      // end of the chunk's data
@@ -124,23 +126,27 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     constexpr int kEv = kSearchS / 16;
     uint32_t ev[kEv];                                             // 2 bits per byte, the first byte of a word highest
     {
-        // my 128 bytes in registers.  At the end of the corpus a lane holds fewer: whole 16-byte slots inside the data are
-        // loaded as such, the slot the data ends in byte by byte, the rest is zero; events behind the data are masked.
-        TextRound<kSearchS / 16> text;
-        if (vlen == kSearchS) text.load(reinterpret_cast<const uint4 *>(bytes + my));
+        // my bytes, 128 at a time in registers.  At the end of the corpus a lane holds fewer: whole 16-byte slots inside the
+        // data are loaded as such, the slot the data ends in byte by byte, the rest is zero; events behind the data are masked.
+        auto round = [&](auto round_index) {
+        constexpr int kR = decltype(round_index)::value;
+        const size_t rb = my + (size_t)128 * kR;
+        const uint32_t rlen = vlen > 128u * kR ? (vlen - 128u * kR < 128u ? vlen - 128u * kR : 128u) : 0u;
+        TextRound<8> text;
+        if (rlen == 128u) text.load(reinterpret_cast<const uint4 *>(bytes + rb));
         else {
             uint32_t off = 0;
             text.for_each_slot_mut([&](uint4 &v) {
-                if (off + 16 <= vlen) v = *reinterpret_cast<const uint4 *>(bytes + my + off);
+                if (off + 16 <= rlen) v = *reinterpret_cast<const uint4 *>(bytes + rb + off);
                 else {
                     uint32_t w[4] = {0, 0, 0, 0};
-                    for (uint32_t k = off; k < vlen && k < off + 16; k++) w[(k - off) >> 2] |= (uint32_t)bytes[my + k] << (8 * ((k - off) & 3));
+                    for (uint32_t k = off; k < rlen && k < off + 16; k++) w[(k - off) >> 2] |= (uint32_t)bytes[rb + k] << (8 * ((k - off) & 3));
                     v = make_uint4(w[0], w[1], w[2], w[3]);
                 }
                 off += 16;
             });
         }
-        int slot = 0;
+        int slot = 8 * kR;
         text.for_each_slot([&](const uint4 &v) {
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
             uint32_t acc = 0;
@@ -171,6 +177,9 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
             // (slot is a compile-time constant after inlining: the lambda is expanded once per slot)
             ev[slot++] = acc;
         });
+        };
+        round(std::integral_constant<int, 0>{});
+        round(std::integral_constant<int, 1>{});
         if (vlen != kSearchS) {                                   // events behind the end of the data do not exist
 #pragma unroll
             for (int i = 0; i < kEv; i++) {
@@ -207,16 +216,19 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
         return line_ord < kStageLines ? st_f[line_ord] : (uint32_t)(first[base_line + line_ord] - F0);
     };
     // kFirst: (line ordinal, start, end); kCount: (line ordinal, count, -); kFill: (slot relative to F0, start, end)
+    // staged packed as start | end << 16 when both fit 16 bits (kNone stays kNone); anything else goes to memory directly
     auto emit = [&](uint32_t idx, uint32_t v0, uint32_t v1) {
-        if (idx < kStageLines) { st_s[idx] = v0; if (MODE != kCount) st_e[idx] = v1; }
-        else {
+        const bool staged = idx < kStageLines;
+        if (MODE == kCount) { if (staged) st_s[idx] = v0; else match_start[base_line + idx] = v0; return; }
+        const bool fits = v0 == kNone || v1 < 0xffffu;            // (v0 <= v1)
+        if (staged) st_s[idx] = v0 == kNone ? kNone : fits ? (v0 | v1 << 16) : kDirect;
+        if (!staged || !fits) {
             const uint64_t at = (MODE == kFill ? F0 : base_line) + idx;
             match_start[at] = v0;
-            if (MODE != kCount) match_end[at] = v1;
+            match_end[at] = v1;
         }
     };
-    // ---- 4. the events in byte order, then the rest of my last line beyond my bytes, then nothing: one loop so that the
-    // queue of walk-back jobs is drained by ONE copy of the walk.  A hit whose start is not known QUEUES a job (lower
+    // ---- 4. the events in byte order, then the rest of my last line beyond my bytes.  A hit whose start is not known QUEUES a job (lower
     // bound, match end, where to put the result, line start): walking back right at the hit would make the lanes of a
     // wave take turns, each waiting through the others' walks (measured: 33 ms for 8 GiB).  Positions are 32-bit
     // offsets from the chunk start from here on.
@@ -255,32 +267,25 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
         owned = ls < my_end_rel;                                  // a line that starts at my_end is the next lane's
         decided = false;
     };
-    uint32_t word_pos = my_rel;                                   // position of byte 0 of ev[0]
-    int words_left = kEv;
-    int phase = 0;                                                // 0: my events, 1: following my last line, 2: done
+    // ---- 4a. my events, word by word (a static loop over the event words, a dynamic one over the events of a word: the
+    // version with one loop body that rotated the words through ev[0] paid 7 extra turns per lane and a longer body)
+#pragma unroll
+    for (int i = 0; i < kEv; i++) {
+        uint32_t m = ev[i];
+        while (m) {
+            const int z = __clz((int)m) >> 1;                     // byte of the word, 0 = first
+            const uint32_t f = (m >> (30 - 2 * z)) & 3u;
+            m &= ~(3u << (30 - 2 * z));
+            const uint32_t pos = my_rel + (uint32_t)(16 * i + z);
+            if (f == 1u) on_newline(pos); else on_hit(pos, f);
+        }
+    }
+    // my last line goes on beyond my bytes and is still open (kFirst: undecided): follow it
+    int phase = (vlen == kSearchS && last_byte != '\n' && owned && !(MODE == kFirst && decided)) ? 1 : 2;   // 1: following, 2: done
     size_t fbyte = my_end;                                        // follow position (word by word while whole 16-byte blocks lie in the data)
     uint4 cur = make_uint4(0, 0, 0, 0), nxt = cur;
+    if (phase == 1 && fbyte + 16 <= nbytes) cur = *reinterpret_cast<const uint4 *>(bytes + fbyte);
     while (phase < 2 || njobs) {
-        // ---- 4a. my events, until they run out or the job queue is full
-        while (phase == 0 && njobs < kJobs) {
-            if (ev[0]) {
-                const int z = __clz((int)ev[0]) >> 1;             // byte of the word, 0 = first
-                const uint32_t f = (ev[0] >> (30 - 2 * z)) & 3u;
-                ev[0] &= ~(3u << (30 - 2 * z));
-                if (f == 1u) on_newline(word_pos + (uint32_t)z); else on_hit(word_pos + (uint32_t)z, f);
-            } else if (words_left > 1) {
-                words_left--;
-                word_pos += 16;
-#pragma unroll
-                for (int i = 0; i + 1 < kEv; i++) ev[i] = ev[i + 1];
-                ev[kEv - 1] = 0;
-            } else {
-                // my last line goes on beyond my bytes and is still open (kFirst: undecided): follow it
-                const bool open_line = vlen == kSearchS && last_byte != '\n' && owned && !(MODE == kFirst && decided);
-                phase = open_line ? 1 : 2;
-                if (open_line && fbyte + 16 <= nbytes) cur = *reinterpret_cast<const uint4 *>(bytes + fbyte);
-            }
-        }
         // ---- 4b. the rest of my last line: sixteen bytes per load, the next sixteen requested before these are stepped
         // (the loop is a chain of memory round trips otherwise), stepped like the forward pass, a text word per turn
         while (phase == 1 && njobs < kJobs) {
@@ -366,17 +371,24 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
 #pragma unroll
         for (int d = 32; d; d >>= 1) tot += __shfl_xor(tot, d, 64);
         const uint32_t staged = tot < kStageLines ? tot : kStageLines;
-        for (uint32_t j = lane; j < staged; j += 64) { match_start[F0 + j] = st_s[j]; match_end[F0 + j] = st_e[j]; }
+        for (uint32_t j = lane; j < staged; j += 64) {
+            const uint32_t v = st_s[j];
+            if (v != kDirect) { match_start[F0 + j] = v & 0xffffu; match_end[F0 + j] = v >> 16; }
+        }
     } else {
         int64_t hi = hi_ord;
         if (hi >= (int64_t)kStageLines) hi = (int64_t)kStageLines - 1;
         for (int64_t j = lo_ord + lane; j <= hi; j += 64) {
-            match_start[base_line + (uint64_t)j] = st_s[j];
-            if (MODE == kFirst) match_end[base_line + (uint64_t)j] = st_e[j];
+            const uint32_t v = st_s[j];
+            if (MODE == kCount) match_start[base_line + (uint64_t)j] = v;
+            else if (v != kDirect) {
+                match_start[base_line + (uint64_t)j] = v == kNone ? kNone : (v & 0xffffu);
+                match_end[base_line + (uint64_t)j] = v == kNone ? kNone : (v >> 16);
+            }
         }
         // the staging array back to its default for the wave's next chunk (only ordinals <= total_nl were touched)
         const uint32_t used = total_nl + 1 < kStageLines ? total_nl + 1 : kStageLines;
-        for (uint32_t j = lane; j < used; j += 64) { st_s[j] = kStageInit; if (MODE == kFirst) st_e[j] = kStageInit; }
+        for (uint32_t j = lane; j < used; j += 64) st_s[j] = kStageInit;
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
@@ -387,9 +399,9 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
 size_t search_chunk_bytes() { return kSearchChunk; }
 static size_t search_table_bytes(const SearchChunkDevice &p) { return ((size_t)p.nrows * p.stride + (p.nr * p.ncls + 1) / 2 + 128 + 64) * 4; }
 // staged entries per wave: what the tables leave of the budget (two workgroups per CU), a multiple of 64, 128 at least
-// (2 arrays for the first match, 1 for the counts, 3 for the fill pass)
+// (one array of packed results or counts; the fill pass also keeps the lines' slot bases)
 static uint32_t search_stage_lines(const SearchChunkDevice &p, int mode) {
-    const size_t tb = search_table_bytes(p), per = (size_t)kSearchWaves * 4 * (mode == kFirst ? 2 : mode == kCount ? 1 : 3);
+    const size_t tb = search_table_bytes(p), per = (size_t)kSearchWaves * 4 * (mode == kFill ? 2 : 1);
     if (tb + per * 128 > kSearchChunkLdsBudget) return 0;
     size_t n = (kSearchChunkLdsBudget - tb) / per;
     n = n / 64 * 64;
@@ -397,7 +409,7 @@ static uint32_t search_stage_lines(const SearchChunkDevice &p, int mode) {
 }
 size_t search_chunks_lds_bytes(const SearchChunkDevice &p) {          // of the most demanding mode (fill)
     const uint32_t n = search_stage_lines(p, kFill);
-    return n ? search_table_bytes(p) + (size_t)kSearchWaves * 12 * n : (size_t)kSearchChunkLdsBudget + 1;
+    return n ? search_table_bytes(p) + (size_t)kSearchWaves * 8 * n : (size_t)kSearchChunkLdsBudget + 1;
 }
 template <int MODE>
 static int launch_search_chunks(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
@@ -405,7 +417,7 @@ static int launch_search_chunks(const SearchChunkDevice &p, const uint8_t *bytes
     if (!nchunks) return 0;
     const uint32_t lines = search_stage_lines(p, MODE);
     if (!lines) return (int)hipErrorInvalidValue;
-    const size_t lds = search_table_bytes(p) + (size_t)kSearchWaves * 4 * (MODE == kFirst ? 2 : MODE == kCount ? 1 : 3) * lines;
+    const size_t lds = search_table_bytes(p) + (size_t)kSearchWaves * 4 * (MODE == kFill ? 2 : 1) * lines;
     static LdsAttr attr;
     hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(search_chunks_kernel<MODE>), lds);
     if (e != hipSuccess) return (int)e;
