@@ -710,3 +710,32 @@ def test_search_all_matches_per_line():
             want = rep.search_all(ln)
             got = [(int(st[first[i] + j]), int(en[first[i] + j])) for j in range(int(cnt[i]))]
             assert got == want, (p, i, len(ln), got[:3], want[:3])
+
+
+def test_search_modes_agree_at_scale():
+    """The three modes of the stripe-wise search kernel on 256 MiB of the URL config (16384 chunks, persistent
+    workgroups that take several each): (1) the first chunk of lines against the oracle's brute force; (2) a line that the
+    pattern accepts as a whole has a match ending inside it; (3) the all-matches pass reproduces the first-match pass:
+    count > 0 exactly where a first match exists, and its first slot holds that match."""
+    import synth
+    n = 256 << 20
+    host = synth.corpus("url", 5, n)
+    dev = torch.from_numpy(host).cuda()
+    corpus = rr.Corpus(dev)
+    r = rr.RRegex(U2)
+    s, e = r.search_corpus(corpus)
+    piece = host[:256 << 10]
+    k = int((piece == 10).sum())
+    ws, we = OracleRegex(U2).search_lines(piece[:int(np.nonzero(piece == 10)[0][-1]) + 1])
+    assert (s[:k].cpu().numpy() == ws).all() and (e[:k].cpu().numpy() == we).all()
+    acc = r.match_corpus(corpus).bool()
+    starts = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), torch.nonzero(dev == 10).flatten() + 1])[:corpus.num_lines]
+    ends = torch.cat([torch.nonzero(dev == 10).flatten(), torch.tensor([n], device="cuda")])[:corpus.num_lines]
+    length = (ends - starts).to(torch.int32)
+    assert bool((e[acc] >= 0).all()) and bool((e[acc] <= length[acc]).all())
+    assert bool(((s >= 0) == (e >= 0)).all()) and bool((s[e >= 0] <= e[e >= 0]).all())
+    cnt, first, st, en = r.search_all(corpus)
+    assert bool(((cnt > 0) == (e >= 0)).all())
+    has = cnt > 0
+    assert torch.equal(st[first[has]], s[has]) and torch.equal(en[first[has]], e[has])
+    assert int(cnt.sum()) == st.numel()
