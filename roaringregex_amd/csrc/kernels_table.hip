@@ -308,10 +308,18 @@ __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t 
     for (int r = 0; r < rounds; r++) {
 #pragma unroll
         for (int i = 0; i < kSlots; i++) {
-            eng.consume_dword(st, clean(buf[i].x), res.bits);
-            eng.consume_dword(st, clean(buf[i].y), res.bits);
-            eng.consume_dword(st, clean(buf[i].z), res.bits);
-            eng.consume_dword(st, clean(buf[i].w), res.bits);
+            if (ONEPASS && __builtin_amdgcn_ballot_w64(((buf[i].x | buf[i].y | buf[i].z | buf[i].w) & 0x80808080u) != 0)) {
+                // some lane of the wave holds a byte >= 0x80 in this slot (one test per 16 bytes; rare on text)
+                eng.consume_dword(st, clean(buf[i].x), res.bits);
+                eng.consume_dword(st, clean(buf[i].y), res.bits);
+                eng.consume_dword(st, clean(buf[i].z), res.bits);
+                eng.consume_dword(st, clean(buf[i].w), res.bits);
+            } else {
+                eng.consume_dword(st, buf[i].x, res.bits);
+                eng.consume_dword(st, buf[i].y, res.bits);
+                eng.consume_dword(st, buf[i].z, res.bits);
+                eng.consume_dword(st, buf[i].w, res.bits);
+            }
             if (res.bits >> 15) res.flush();                 // <= 16 more results fit before the next check
         }
         if ((r & 3) == 3) res.flush();
