@@ -398,6 +398,7 @@ struct rrx_corpus {
 };
 
 static constexpr size_t kLongStringBytes = 32 * 1024;   // shorter single strings stay on one lane
+static constexpr uint32_t kLongNfaMaxBits = 256;        // NFA engines: chunk relations cost bytes x positions lane steps
 
 extern "C" {
 
@@ -565,6 +566,10 @@ int rrx_corpus_create_ex(int device, const void *d_bytes, size_t nbytes, uint32_
         const size_t avg_line = nbytes / c->nlines;
         uint32_t want = c->stripe;
         while (want < dev::kMaxStripe && avg_line * 16 > want && nbytes / (2 * (size_t)want) >= ((size_t)1 << 17)) want *= 2;
+        // Short lines want shorter stripes: a workgroup's 1024 lanes hold 1024 * stripe / avg_line lines, and beyond the
+        // 131072 its LDS result window is sure to hold (16 KiB) the result words go to memory one atomic at a time
+        // (k<n> lines of 5.4 bytes, 8 GiB: 4 KiB stripes 3.69 TB/s, 1 KiB stripes 4.53; profiles/r02_short_line_stripes.txt).
+        while (want > dev::kMinStripe && (avg_line + 1) * 128 < want) want /= 2;
         if (want != c->stripe) {
             rrx_corpus_free(c);
             return rrx_corpus_create_ex(device, d_bytes, nbytes, want, stream, out);
@@ -816,6 +821,13 @@ static int match_string_with(const rrx_regex *re, int device, const DeviceTables
         if (le) return hip_fail((hipError_t)le, "match_long launch");
         return RRX_OK;
     }
+    if (re->engine == RRX_ENGINE_NFA && nbytes >= kLongStringBytes && t->nfa.nbits <= kLongNfaMaxBits) {
+        uint32_t chunk = 0, nchunks = 0;
+        (void)dev::long_nfa_scratch_bytes(t->nfa, nbytes, &chunk, &nchunks);
+        int le = dev::match_long_nfa(t->nfa, d_bytes, nbytes, chunk, nchunks, scratch, d_accept, st);
+        if (le) return hip_fail((hipError_t)le, "match_long_nfa launch");
+        return RRX_OK;
+    }
     const uint64_t off[2] = {0, nbytes};
     uint64_t *d_off = reinterpret_cast<uint64_t *>(scratch);
     hipError_t e = hipMemcpyAsync(d_off, off, sizeof off, hipMemcpyHostToDevice, st);
@@ -828,6 +840,10 @@ static size_t match_string_scratch_bytes(const rrx_regex *re, const DeviceTables
     if (table_engine && nbytes >= kLongStringBytes && t->dfa.nstates && t->dfa.nstates <= dev::kLongMaxStates) {
         uint32_t chunk = 0;
         return dev::long_scratch_bytes(t->dfa.nstates, nbytes, &chunk);
+    }
+    if (re->engine == RRX_ENGINE_NFA && nbytes >= kLongStringBytes && t->nfa.nbits <= kLongNfaMaxBits) {
+        uint32_t chunk = 0, nchunks = 0;
+        return dev::long_nfa_scratch_bytes(t->nfa, nbytes, &chunk, &nchunks);
     }
     return 2 * sizeof(uint64_t);
 }

@@ -208,6 +208,11 @@ constexpr uint32_t kLongGroup = 128;             // maps composed per workgroup 
 size_t long_scratch_bytes(uint32_t nstates, size_t nbytes, uint32_t *chunk);
 int match_long_dfa(const DfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t chunk, void *scratch, uint8_t *accept,
                    void *stream);
+// One long string on the NFA lane engines: per chunk the rows "positions reached from position p" (lane = (chunk, p)), then
+// the relations applied in order to {initial}.  `scratch` holds the rows (long_nfa_scratch_bytes).
+size_t long_nfa_scratch_bytes(const NfaDevice &p, size_t nbytes, uint32_t *chunk, uint32_t *nchunks);
+int match_long_nfa(const NfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t chunk, uint32_t nchunks, void *scratch, uint8_t *accept,
+                   void *stream);
 int match_extents_nfa(const NfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim,
                       uint8_t *accept, void *stream);
 int match_extents_dfa(const DfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim,

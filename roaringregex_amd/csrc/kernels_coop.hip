@@ -345,6 +345,20 @@ RRX_NFA_PARTS(match_onepass_nfa,
 RRX_NFA_PARTS(match_extents_nfa,
               (const NfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim, uint8_t *accept, void *stream),
               (p, bytes, off, nitems, trim, accept, stream))
+RRX_NFA_PARTS(match_long_nfa,
+              (const NfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t chunk, uint32_t nchunks, void *scratch, uint8_t *accept, void *stream),
+              (p, bytes, nbytes, chunk, nchunks, scratch, accept, stream))
 #undef RRX_NFA_PARTS
+// chunking of one long string for the NFA form: at most 65536 chunks of 1 KiB or more, and at most 256 MiB of rows
+// (chunks x positions x words x 4 bytes); the composition levels ping-pong between the rows and a second area of half
+// their size (rounded up to a whole relation)
+size_t long_nfa_scratch_bytes(const NfaDevice &p, size_t nbytes, uint32_t *chunk, uint32_t *nchunks) {
+    uint32_t c = 1024;
+    const size_t per_chunk = (size_t)p.nbits * p.W * 4;
+    while ((nbytes + c - 1) / c > 65536 || ((nbytes + c - 1) / c) * per_chunk > ((size_t)256 << 20)) c <<= 1;
+    *chunk = c;
+    *nchunks = (uint32_t)((nbytes + c - 1) / c);
+    return ((size_t)*nchunks + ((size_t)*nchunks + 1) / 2) * per_chunk;
+}
 }  // namespace dev
 }  // namespace rrx
