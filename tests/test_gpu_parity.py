@@ -474,6 +474,14 @@ def test_one_shot_entry_reads_the_text_once_and_agrees_with_the_indexed_path():
                     assert bad.size == 0, (n, variant, last, r.engine_name, "first bad line", int(bad[0]))
                 if n > 100000:
                     break
+    # extremes: nothing but newlines (one string per byte: every lane's stream fills its slab), no newline at all (one
+    # string that every lane but the first merely follows), one-byte lines
+    for blob in (b"\n" * ((1 << 20) + 3), b"ab" * 300_000, b"a\n" * 400_001, b"abb\n" + b"b" * 70_000 + b"\nabb"):
+        data = np.frombuffer(blob, dtype=np.uint8).copy()
+        want = o.match_lines(data)
+        for e in (rr.ENGINE_AUTO, rr.ENGINE_DFA, rr.ENGINE_NFA):
+            bits, nlines = rr.RRegex(p, e).match_device_bits(torch.from_numpy(data.copy()).cuda())
+            assert nlines == len(want) and (_bits_to_bytes(bits, nlines) == want).all(), (len(blob), e)
     # a bitmap that is too small is reported, not overrun
     data = np.frombuffer(b"a\n" * 5000, dtype=np.uint8).copy()
     with pytest.raises(rr.RRegexError, match="too small"):
