@@ -44,7 +44,7 @@ WORKLOADS = {
 
 
 ENGINES = {"auto": "ENGINE_AUTO", "nfa": "ENGINE_NFA", "dfa": "ENGINE_DFA", "dfa2": "ENGINE_DFA2", "wave": "ENGINE_NFA_WAVE",
-           "dfa-global": "ENGINE_DFA_GLOBAL"}
+           "dfa-global": "ENGINE_DFA_GLOBAL", "block": "ENGINE_NFA_BLOCK"}
 
 
 def patterns():

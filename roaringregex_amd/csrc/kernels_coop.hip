@@ -161,8 +161,10 @@ __global__ __launch_bounds__(256) void match_extents_group_kernel(GroupNfaDevice
 //   * exception edges: kept SPARSE (CSR lists in HBM/L2; dense rows would take N*N/8 bytes), a lane walks the live
 //     exception positions of its 64 and ORs the target bits into an LDS accumulator, which the owning lanes merge and
 //     clear after the barrier - the set stays dense where it is populated, the rules that reach across it are lists;
-//   * the verdict is a barrier-with-OR, only on '\n' / end of string.
-// B rows are per byte class in HBM/L2, [class][lane] 8-byte words, read coalesced.  Everything is workgroup-uniform.
+//   * the verdict is a barrier-with-OR, only on '\n' / end of string;
+//   * a wave = a block of 4096 positions; a block that is empty and receives nothing skips its row read and its step.
+// B rows are per byte class in HBM/L2, [class][lane] 8-byte words, read coalesced.  Control flow is workgroup-uniform
+// up to that per-wave skip.
 struct BlockNfa {
     uint32_t fin0, fin1, self0, self1, exc0, exc1;
     const uint2 *__restrict__ rows;        // HBM/L2 [ncls][T]
@@ -204,16 +206,24 @@ struct BlockNfa {
     // c is the same in every lane of the workgroup
     template <bool LINE>
     __device__ __forceinline__ void advance(uint32_t &s0, uint32_t &s1, uint32_t c) {
-        const uint2 b = rows[(size_t)cls[c] * T + lane];
         uint32_t *tp = top + par * T, *acc = texc + par * 2 * T;
         tp[lane] = s1;
         if (any_exc) { scatter(s0 & exc0, (uint32_t)lane * 64u, acc); scatter(s1 & exc1, (uint32_t)lane * 64u + 32u, acc); }
         __syncthreads();
         const uint32_t below = lane ? tp[lane - 1] : (LINE ? 0x80000000u : 0u);
-        uint32_t t0 = __builtin_amdgcn_alignbit(s0, below, 31) | (s0 & self0);
-        uint32_t t1 = __builtin_amdgcn_alignbit(s1, s0, 31) | (s1 & self1);
-        if (any_exc) { t0 |= acc[2 * lane]; t1 |= acc[2 * lane + 1]; acc[2 * lane] = 0; acc[2 * lane + 1] = 0; }
-        s0 = t0 & b.x; s1 = t1 & b.y;
+        uint32_t x0 = 0, x1 = 0;
+        if (any_exc) { x0 = acc[2 * lane]; x1 = acc[2 * lane + 1]; }
+        // A wave is a block of 4096 positions.  If none of them is live and nothing flows in - no bit from the lane
+        // below, no exception target - the block stays empty whatever the byte: the wave skips its B row (8 bytes per lane
+        // from HBM/L2) and the step.  Large automata with small live sets (a few of many alternatives alive) run mostly
+        // on this path; the set is dense only where it is populated.
+        if (__ballot((s0 | s1 | below | x0 | x1) != 0)) {
+            const uint2 b = rows[(size_t)cls[c] * T + lane];
+            uint32_t t0 = __builtin_amdgcn_alignbit(s0, below, 31) | (s0 & self0) | x0;
+            uint32_t t1 = __builtin_amdgcn_alignbit(s1, s0, 31) | (s1 & self1) | x1;
+            if (any_exc && (x0 | x1)) { acc[2 * lane] = 0; acc[2 * lane + 1] = 0; }
+            s0 = t0 & b.x; s1 = t1 & b.y;
+        }
         par ^= 1u;
     }
 };

@@ -523,6 +523,8 @@ def test_block_cooperative_engine_beyond_4096_positions():
     assert list(got) == [int(x) for x in want]
     for t in lines[:5]:
         assert (r.get_acceptance_iter(t).advance().value() is not None) == o.accepts(t)
+    # (lines of b only keep a single position alive: every 4096-position block but the first is empty and skips its step;
+    # lines of a only fill the set: both sides of the per-wave skip are in `lines`)
 
 
 def test_match_host_pipeline_equals_resident_path():
