@@ -62,8 +62,9 @@ struct GroupNfa {
         uint32_t t1 = __builtin_amdgcn_alignbit(s1, s0, 31) | (s1 & self1);
         if (any_exc) {
             uint32_t e0 = s0 & exc0, e1 = s1 & exc1;
-            uint64_t mine = __ballot((e0 | e1) != 0) & gmask;
-            while (__ballot(mine != 0)) {                        // (the condition is the same in every active lane)
+            uint64_t live = __ballot((e0 | e1) != 0);            // (scalar: the lanes of the wave with a live exception position)
+            while (live) {                                       // the same in every active lane
+                const uint64_t mine = live & gmask;
                 const int src = mine ? __ffsll((long long)mine) - 1 : lane;
                 const uint32_t w0 = __shfl(e0, src, 64), w1 = __shfl(e1, src, 64);
                 if (mine) {
@@ -72,7 +73,7 @@ struct GroupNfa {
                     const uint2 row = X[(size_t)xidx[(src - gbase) * 64 + bit] * G + lig];
                     t0 |= row.x; t1 |= row.y;
                 }
-                mine = __ballot((e0 | e1) != 0) & gmask;
+                live = __ballot((e0 | e1) != 0);
             }
         }
         s0 = t0 & b.x; s1 = t1 & b.y;
