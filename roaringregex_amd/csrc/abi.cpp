@@ -167,7 +167,7 @@ struct rrx_regex {
             t.chunk.start_off = search_line.start * row_bytes; t.chunk.skip_off = search_line.skip * row_bytes;
             t.chunk.nr = NR; t.chunk.ncls = K; t.chunk.start_r = search_rev.start;
         }
-        HIP_TRY(hipMalloc(&t.blob, host.size()));
+        HIP_TRY(hipMalloc(&t.blob, host.size() + 16));
         hipError_t e = hipMemcpy(t.blob, host.data(), host.size(), hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipFree(t.blob); return hip_fail(e, "search table upload"); }
         const uint8_t *base = static_cast<const uint8_t *>(t.blob);

@@ -40,6 +40,33 @@ __device__ __forceinline__ uint64_t line_of(uint64_t base) { return base & ~kFre
 // (measured -47 %, profiles/r01_v7_result_path_probes.txt).
 __device__ __forceinline__ uint4 load_text(const uint4 *p) { return *p; }
 
+// Workgroup copy of a device table into LDS, 16 bytes per lane per access and kBatch accesses in flight per lane
+// (instead of one dword per trip of a `for (i = tid; i < n; i += blockDim.x)` loop).  Measured neutral on the stride-2
+// engine, same box, old against new build (profiles/r02_headline_ab.txt): the table copy is not where a launch's fixed
+// cost goes.  `add` goes onto every dword (tables whose entries hold LDS addresses).  src and dst are 16-byte aligned,
+// nbytes is a multiple of 4.
+template <int kBatch = 4>
+__device__ __forceinline__ void copy_table_to_lds(void *dst_lds, const void *src, uint32_t nbytes, uint32_t add = 0) {
+    uint4 *d = static_cast<uint4 *>(dst_lds);
+    const uint4 *s = static_cast<const uint4 *>(src);
+    const uint32_t nvec = nbytes / 16;
+    for (uint32_t base = threadIdx.x; base < nvec; base += kBatch * blockDim.x) {
+        uint4 v[kBatch];
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            const uint32_t i = base + k * blockDim.x;
+            if (i < nvec) v[k] = s[i];
+        }
+#pragma unroll
+        for (int k = 0; k < kBatch; k++) {
+            const uint32_t i = base + k * blockDim.x;
+            if (i < nvec) d[i] = make_uint4(v[k].x + add, v[k].y + add, v[k].z + add, v[k].w + add);
+        }
+    }
+    const uint32_t tail = nvec * 4 + threadIdx.x;                 // the last 0..3 dwords
+    if (tail < nbytes / 4) static_cast<uint32_t *>(dst_lds)[tail] = static_cast<const uint32_t *>(src)[tail] + add;
+}
+
 // One round of a lane's text: N 16-byte slots requested as ONE burst (they merge into one request per 128-byte line)
 // and consumed in order.  The slots are members reached through compile-time recursion, never an indexed array: an
 // engine whose step contains a loop keeps the compiler from unrolling a slot loop, and an indexed buffer then lives in

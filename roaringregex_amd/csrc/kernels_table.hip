@@ -35,7 +35,7 @@ struct LineDfaEngine {
         // In the SDWA form the low half of an entry is the ABSOLUTE LDS address of the next row, so that
         // e.word[0] + 4*c is the address to read, with no base to add per byte.
         const uint32_t base = (WIDE && !CLAMP) ? (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)lds : 0u;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) t[i] = p.table[i] + base;
+        copy_table_to_lds(t, p.table, (uint32_t)n * 4u, base);
         if (!WIDE) {
             uint8_t *c = lds + (size_t)n * 4;
             for (int i = threadIdx.x; i < 256; i += blockDim.x) c[i] = p.cls[i];
@@ -192,13 +192,9 @@ struct Dfa2 {
 
     __host__ __device__ static size_t lds_bytes(const Dfa2Device &p) { return (size_t)p.nrows * p.stride * 4; }     // dynamic part: T2
     __device__ void load(const Dfa2Device &p, uint16_t *p_lds, uint8_t *t_lds) {
-        uint32_t *pl = reinterpret_cast<uint32_t *>(p_lds);
-        const uint32_t *ps = reinterpret_cast<const uint32_t *>(p.P);
-        for (int i = threadIdx.x; i < (int)(kDfa2PBytes / 4); i += blockDim.x) pl[i] = ps[i];
-        uint32_t *t = reinterpret_cast<uint32_t *>(t_lds);
         const uint32_t tbase = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)t_lds;
-        const int n = (int)(p.nrows * p.stride);
-        for (int i = threadIdx.x; i < n; i += blockDim.x) t[i] = p.T2[i] + tbase;
+        copy_table_to_lds(p_lds, p.P, kDfa2PBytes);
+        copy_table_to_lds(t_lds, p.T2, p.nrows * p.stride * 4, tbase);
         const uint32_t copy = (threadIdx.x & ((1u << p.rep_log2) - 1u)) * 4u;
         P = p_lds;
         start_off = p.start_off + tbase + copy;
