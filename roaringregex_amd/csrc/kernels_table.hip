@@ -404,9 +404,14 @@ __global__ __launch_bounds__(256) void compact_streams_kernel(const uint32_t *__
                                                                uint32_t *__restrict__ accept_bits, size_t cap_words,
                                                                uint32_t *__restrict__ overflow) {
     __shared__ uint32_t window[kCompactWindowWords];
-    for (uint32_t i = threadIdx.x; i < kCompactWindowWords; i += 256) window[i] = 0;
     const size_t g0 = (size_t)blockIdx.x * 256;
+    const size_t g1 = g0 + 256 < nstripes ? g0 + 256 : nstripes;
     const uint64_t window_word = line_of(stripe_base[g0]) >> 5;          // g0 < nstripes: the grid is sized that way
+    // the words this workgroup's streams can reach: up to the line the next workgroup starts in, one more for the
+    // extra result of the last stripe (stripe_base has nstripes + 1 entries); only those are cleared and written out
+    const uint64_t span = (line_of(stripe_base[g1]) >> 5) - window_word + 2;
+    const uint32_t used = span < kCompactWindowWords ? (uint32_t)span : kCompactWindowWords;
+    for (uint32_t i = threadIdx.x; i < used; i += 256) window[i] = 0;
     __syncthreads();
     const size_t g = g0 + threadIdx.x;
     if (g < nstripes) {
@@ -420,7 +425,7 @@ __global__ __launch_bounds__(256) void compact_streams_kernel(const uint32_t *__
             if (!v) return;
             if (word >= cap_words) { atomicOr(overflow, 1u); return; }
             const uint64_t rel = word - window_word;
-            if (rel < kCompactWindowWords) atomicOr(&window[(uint32_t)rel], v);
+            if (rel < used) atomicOr(&window[(uint32_t)rel], v);
             else atomicOr(&accept_bits[word], v);
         };
         for (uint32_t k = 0; k * 32 < n; k++) {
@@ -434,7 +439,7 @@ __global__ __launch_bounds__(256) void compact_streams_kernel(const uint32_t *__
         }
     }
     __syncthreads();
-    for (uint32_t i = threadIdx.x; i < kCompactWindowWords; i += 256) {
+    for (uint32_t i = threadIdx.x; i < used; i += 256) {
         const uint32_t v = window[i];
         if (v) atomicOr(&accept_bits[window_word + i], v);
     }
@@ -511,41 +516,69 @@ __global__ __launch_bounds__(256) void scan_chunk_sums_kernel(const uint32_t *__
     __syncthreads();
     if (threadIdx.x == 0) sums[blockIdx.x] = part[0] + part[1] + part[2] + part[3];
 }
+// exclusive prefix over the workgroup of one value per thread (NW waves): shuffles inside a wave, the NW wave totals
+// through LDS.  (The first version let thread 0 walk the partial sums one by one: 10-50 us per scan kernel, as much as
+// the one-shot entry's compaction.)
+template <int NW>
+__device__ __forceinline__ uint64_t block_exclusive_scan(uint64_t v, uint64_t *wave_tot, uint64_t &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint64_t inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint64_t off = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < NW; w++) {
+        const uint64_t t = wave_tot[w];
+        if (w < wave) off += t;
+        tot += t;
+    }
+    total = tot;
+    return off + inc - v;
+}
 __global__ __launch_bounds__(1024) void scan_sums_kernel(uint64_t *__restrict__ sums, size_t nchunks, uint64_t *__restrict__ total) {
-    __shared__ uint64_t sh[1024];
+    __shared__ uint64_t wave_tot[16];
     const size_t per = (nchunks + 1023) / 1024;
     const size_t lo = threadIdx.x * per < nchunks ? threadIdx.x * per : nchunks, hi = lo + per < nchunks ? lo + per : nchunks;
     uint64_t s = 0;
     for (size_t i = lo; i < hi; i++) s += sums[i];
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t run = 0;
-        for (int i = 0; i < 1024; i++) { uint64_t v = sh[i]; sh[i] = run; run += v; }
-        *total = run;
-    }
-    __syncthreads();
-    uint64_t run = sh[threadIdx.x];
+    uint64_t all;
+    uint64_t run = block_exclusive_scan<16>(s, wave_tot, all);
+    if (threadIdx.x == 0) *total = all;
     for (size_t i = lo; i < hi; i++) { uint64_t v = sums[i]; sums[i] = run; run += v; }
 }
 __global__ __launch_bounds__(256) void scan_chunks_kernel(const uint32_t *__restrict__ counts, size_t n, const uint64_t *__restrict__ sums,
                                                            uint64_t *__restrict__ base) {
-    __shared__ uint64_t sh[256];
-    const size_t lo = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * (kScanChunk / 256);
-    uint64_t s = 0;
-    for (size_t i = lo; i < lo + kScanChunk / 256 && i < n; i++) s += counts[i] & kCountMask;
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t run = sums[blockIdx.x];
-        for (int i = 0; i < 256; i++) { uint64_t v = sh[i]; sh[i] = run; run += v; }
+    __shared__ uint64_t wave_tot[4];
+    constexpr int kPer = kScanChunk / 256;
+    const size_t lo = (size_t)blockIdx.x * kScanChunk + (size_t)threadIdx.x * kPer;
+    uint32_t c[kPer];
+    uint32_t before = 0;                                   // the count word in front of mine (its kEndsOnNewline flag)
+    if (lo + kPer <= n) {
+        const uint4 *src = reinterpret_cast<const uint4 *>(counts + lo);      // lo is a multiple of kPer = 16 words
+#pragma unroll
+        for (int k = 0; k < kPer / 4; k++) { const uint4 v = src[k]; c[4 * k] = v.x; c[4 * k + 1] = v.y; c[4 * k + 2] = v.z; c[4 * k + 3] = v.w; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kPer; k++) c[k] = lo + k < n ? counts[lo + k] : 0u;
     }
-    __syncthreads();
-    uint64_t run = sh[threadIdx.x];
-    for (size_t i = lo; i < lo + kScanChunk / 256 && i < n; i++) {
-        const bool fresh = i == 0 || (counts[i - 1] & kEndsOnNewline);
-        base[i] = run | (fresh ? kFreshStripe : 0);
-        run += counts[i] & kCountMask;
+    if (lo && lo < n) before = counts[lo - 1];
+    uint64_t s = 0;
+#pragma unroll
+    for (int k = 0; k < kPer; k++) s += c[k] & kCountMask;
+    uint64_t all;
+    uint64_t run = sums[blockIdx.x] + block_exclusive_scan<4>(s, wave_tot, all);
+#pragma unroll
+    for (int k = 0; k < kPer; k++) {
+        if (lo + k < n) {
+            const bool fresh = lo + k == 0 || ((k ? c[k - 1] : before) & kEndsOnNewline);
+            base[lo + k] = run | (fresh ? kFreshStripe : 0);
+        }
+        run += c[k] & kCountMask;
     }
 }
 
