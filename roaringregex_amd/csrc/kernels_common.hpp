@@ -151,15 +151,19 @@ struct ResultsT {
 typedef ResultsT<false> Results;
 
 // One-pass mode (rrx_match_device: no line index exists yet): a lane does not know the index of its first line, so it
-// packs its verdicts from bit 0 of its OWN stream and stores the stream word by word into the workgroup's slab in HBM,
-// slab[word][lane] (word k of the lanes of a workgroup is one contiguous row).  The per-stripe newline counts the lanes
+// packs its verdicts from bit 0 of its OWN stream and stores the stream word by word into the slab in HBM,
+// slab[word][stripe]: word k of ALL stripes is one dense row (rows padded to whole workgroups); a lane of 4 KiB writes
+// about three words.  (A slab per workgroup, slab[workgroup][word][lane], put those few rows 528 KiB apart; the dense
+// rows measure 2-3 % better on average, within a process-to-process spread of +-5 % that both layouts show:
+// profiles/r02_one_shot_breakdown.txt.)  The per-stripe newline counts the lanes
 // write on the side are scanned afterwards, and compact_streams_kernel shifts every lane's stream to its place in the
 // accept bitmap.  bit k of a lane's stream = the k-th line end it saw (the first one belongs to the lane before if the
 // stripe starts inside a line: the compaction drops it, as ResultsT does with drop_first).
 struct LocalResults {
     uint32_t bits = 1, outw = 0, fill = 0, seen = 0, k = 0;
-    uint32_t *__restrict__ dst;            // &slab[0][lane]
-    __device__ __forceinline__ void begin(uint32_t *slab_lane) { dst = slab_lane; }
+    uint32_t *__restrict__ dst;            // &slab[0][my stripe]
+    uint32_t row;                          // stripes per slab row
+    __device__ __forceinline__ void begin(uint32_t *slab_lane, uint32_t row_stripes) { dst = slab_lane; row = row_stripes; }
     __device__ __forceinline__ void push(uint32_t nl, uint32_t acc) { bits = (bits << nl) | acc; }
     __device__ __forceinline__ void flush() {
         const int n = 31 - __clz((int)bits);
@@ -168,7 +172,7 @@ struct LocalResults {
             outw |= rev << fill;
             uint32_t nf = fill + (uint32_t)n;
             if (nf >= 32u) {
-                dst[(size_t)k * kThreads] = outw;
+                dst[(size_t)k * row] = outw;
                 k++;
                 outw = fill ? rev >> (32u - fill) : 0u;
                 nf -= 32u;
@@ -180,7 +184,7 @@ struct LocalResults {
     }
     __device__ __forceinline__ void finish() {
         flush();
-        if (fill) dst[(size_t)k * kThreads] = outw;
+        if (fill) dst[(size_t)k * row] = outw;
     }
 };
 constexpr uint32_t kCountMask = 0x3fffffffu;             // counts[g]: bits 0..29 = '\n' in stripe g
@@ -217,7 +221,7 @@ __device__ __forceinline__ void match_stripes_body(const Program &prog, const ui
     bool fresh = true;
     typename std::conditional<ONEPASS, LocalResults, ResultsT<Engine::kStaged>>::type res;
     if constexpr (ONEPASS) {
-        res.begin(slabs + (size_t)blockIdx.x * slab_words_per_lane(stripe) * kThreads + threadIdx.x);
+        res.begin(slabs + g, gridDim.x * kThreads);
     } else {
         const uint64_t my_base = stripe_base[g];
         fresh = (my_base & kFreshStripe) != 0;

@@ -276,7 +276,7 @@ __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t 
     bool fresh = true;
     typename std::conditional<ONEPASS, LocalResults, ResultsT<true>>::type res;
     if constexpr (ONEPASS) {
-        res.begin(slabs + (size_t)blockIdx.x * slab_words_per_lane(stripe) * kThreads + threadIdx.x);
+        res.begin(slabs + g, gridDim.x * kThreads);
     } else {
         const uint64_t my_base = stripe_base[g];
         fresh = (my_base & kFreshStripe) != 0;
@@ -304,7 +304,11 @@ __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t 
     for (int r = 0; r < rounds; r++) {
 #pragma unroll
         for (int i = 0; i < kSlots; i++) {
-            if (ONEPASS && __builtin_amdgcn_ballot_w64(((buf[i].x | buf[i].y | buf[i].z | buf[i].w) & 0x80808080u) != 0)) {
+#ifdef RRX_PROBE_ONEPASS_NO_HIGH_CHECK
+            if (false) {
+#else
+            if (ONEPASS && __builtin_expect(__builtin_amdgcn_ballot_w64(((buf[i].x | buf[i].y | buf[i].z | buf[i].w) & 0x80808080u) != 0) != 0, 0)) {
+#endif
                 // some lane of the wave holds a byte >= 0x80 in this slot (one test per 16 bytes; rare on text)
                 eng.consume_dword(st, clean(buf[i].x), res.bits);
                 eng.consume_dword(st, clean(buf[i].y), res.bits);
@@ -420,7 +424,8 @@ __global__ __launch_bounds__(256) void compact_streams_kernel(const uint32_t *__
         const uint64_t b = stripe_base[g];
         const uint64_t base = line_of(b);
         const bool fresh = (b & kFreshStripe) != 0;
-        const uint32_t *src = slabs + (g / kThreads) * slab_words_per_lane(stripe) * kThreads + (g % kThreads);
+        const size_t row = (nstripes + kThreads - 1) / kThreads * kThreads;     // slab[k][stripe], rows padded to whole workgroups
+        const uint32_t *src = slabs + g;
         auto put = [&](uint64_t word, uint32_t v) {
             if (!v) return;
             if (word >= cap_words) { atomicOr(overflow, 1u); return; }
@@ -429,7 +434,7 @@ __global__ __launch_bounds__(256) void compact_streams_kernel(const uint32_t *__
             else atomicOr(&accept_bits[word], v);
         };
         for (uint32_t k = 0; k * 32 < n; k++) {
-            uint32_t v = src[(size_t)k * kThreads];
+            uint32_t v = src[(size_t)k * row];
             if (n - k * 32 < 32) v &= (1u << (n - k * 32)) - 1u;
             if (k == 0 && !fresh) v &= ~1u;                          // that line belongs to the lane before me
             const uint64_t bit = base + (uint64_t)k * 32;
