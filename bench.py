@@ -356,7 +356,18 @@ def main():
             cnt, first, s, e = regex.search_all(corpus)
             torch.cuda.synchronize()
             res["search"]["all_matches"] = {"GBs": round(nbytes / (time.perf_counter() - t0) / 1e9, 2), "matches": int(s.numel())}
+            total = int(s.numel())
             del cnt, first, s, e
+            # the same through the one-call entry (rrx_search_all: one launch, look-back over the chunks' match counts),
+            # arrays sized for the result (a caller that guesses too low pays a second call)
+            first, s, e = regex.search_all_fused(corpus, cap=total)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(3):
+                first, s, e = regex.search_all_fused(corpus, cap=total)
+            torch.cuda.synchronize()
+            res["search"]["all_matches_one_call"] = {"GBs": round(3 * nbytes / (time.perf_counter() - t0) / 1e9, 2), "matches": int(s.numel())}
+            del first, s, e
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(pattern, host)
         print(json.dumps(res), flush=True)

@@ -105,6 +105,14 @@ int rrx_search_all_count(const rrx_regex *re, const rrx_corpus *corpus, uint32_t
 int rrx_search_all_fill(const rrx_regex *re, const rrx_corpus *corpus, const uint64_t *d_first, uint32_t *d_start,
                         uint32_t *d_end, void *stream);
 
+/* The same in ONE call and one pass over the text: d_first[i] (u64, nlines + 1 entries, d_first[nlines] = *total) =
+ * slot of the first match of string i, the matches of string i at d_start/d_end[d_first[i] .. d_first[i + 1]).  The
+ * match arrays hold `cap` entries: matches beyond are counted, not written - if *total > cap call again with arrays of
+ * *total entries (d_first is complete either way).  Synchronous (returns *total).  Calls on one corpus must not
+ * overlap (they share the corpus' scratch).                                                                        */
+int rrx_search_all(const rrx_regex *re, const rrx_corpus *corpus, uint64_t *d_first, uint32_t *d_start, uint32_t *d_end,
+                   size_t cap, size_t *total, void *stream);
+
 /* explicit extents: item i = d_bytes[d_off[i] .. d_off[i+1] - trim); '\n' is an ordinary character here */
 int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, const uint64_t *d_off, size_t nitems,
                       uint32_t trim, uint8_t *d_accept, void *stream);

@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "rrx_engine", "rrx_engine_name", "rrx_useful_states", "rrx_byte_classes", "rrx_words_per_set", "rrx_accepts_empty",
     "rrx_program_words",
     "rrx_corpus_create", "rrx_corpus_create_ex", "rrx_corpus_stripe_bytes", "rrx_corpus_num_lines", "rrx_corpus_num_bytes", "rrx_corpus_free", "rrx_corpus_bitmap_words",
-    "rrx_match_corpus", "rrx_match_device", "rrx_search_corpus", "rrx_search_all_count", "rrx_search_all_fill", "rrx_bitmap_to_bytes",
+    "rrx_match_corpus", "rrx_match_device", "rrx_search_corpus", "rrx_search_all_count", "rrx_search_all_fill", "rrx_search_all", "rrx_bitmap_to_bytes",
     "rrx_match_extents", "rrx_match_string", "rrx_match_host", "rrx_match_cstr",
 )
 
@@ -80,6 +80,7 @@ def _load():
         "rrx_search_corpus": (i32, [vp, vp, vp, vp, vp]),
         "rrx_search_all_count": (i32, [vp, vp, vp, vp]),
         "rrx_search_all_fill": (i32, [vp, vp, vp, vp, vp, vp]),
+        "rrx_search_all": (i32, [vp, vp, vp, vp, vp, sz, C.POINTER(sz), vp]),
         "rrx_match_host": (i32, [vp, i32, vp, sz, vp, sz, C.POINTER(sz)]),
         "rrx_match_cstr": (i32, [vp, i32, C.c_char_p, C.POINTER(i32), C.POINTER(sz)]),
     }
@@ -297,6 +298,27 @@ class RRegex:
                 _check(_L.rrx_search_all_fill(self._h, corpus._h, C.c_void_p(first.data_ptr()), C.c_void_p(start.data_ptr() if total else 0),
                                               C.c_void_p(end.data_ptr() if total else 0), _stream_ptr(stream)))
         return count, first, start, end
+
+    def search_all_fused(self, corpus, cap=None, stream=None):
+        """The same result through the one-call entry (rrx_search_all: one pass over the text) ->
+        (first[n + 1] int64 CSR offsets, start[total] int32, end[total] int32).  cap: entries to provide for at first
+        (default: two per string); the call is repeated with the exact size if there are more."""
+        import torch
+        n = corpus.num_lines
+        dev = corpus.data.device
+        with _on(corpus.device, stream):
+            first = torch.empty(n + 1, dtype=torch.int64, device=dev)
+            cap = int(cap) if cap is not None else 2 * n + 1024
+            while True:
+                start = torch.empty(cap, dtype=torch.int32, device=dev)
+                end = torch.empty(cap, dtype=torch.int32, device=dev)
+                total = C.c_size_t(0)
+                _check(_L.rrx_search_all(self._h, corpus._h, C.c_void_p(first.data_ptr()), C.c_void_p(start.data_ptr() if cap else 0),
+                                         C.c_void_p(end.data_ptr() if cap else 0), cap, C.byref(total), _stream_ptr(stream)))
+                if total.value <= cap:
+                    break
+                cap = total.value
+        return first, start[:total.value], end[:total.value]
 
     def match_extents(self, data, offsets, trim=0, out=None, stream=None):
         """item i = data[offsets[i] : offsets[i+1] - trim]; '\\n' is an ordinary character."""

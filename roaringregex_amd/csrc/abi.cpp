@@ -395,6 +395,7 @@ struct rrx_corpus {
     // stripe-wise search: newline prefix per search chunk (the stripe index itself when the stripe is that size)
     mutable uint64_t *d_chunk_base = nullptr;   // [nchunks + 1 + scan scratch]; owned unless it aliases d_base
     mutable size_t nchunks = 0;
+    mutable void *d_all_scratch = nullptr;      // rrx_search_all: per-chunk status words, total, ticket (zeroed per call)
 };
 
 static constexpr size_t kLongStringBytes = 32 * 1024;   // shorter single strings stay on one lane
@@ -588,6 +589,7 @@ void rrx_corpus_free(rrx_corpus *c) {
     if (c->d_base) (void)hipFree(c->d_base);
     if (c->d_line_off) (void)hipFree(c->d_line_off);
     if (c->d_chunk_base && c->d_chunk_base != c->d_base) (void)hipFree(c->d_chunk_base);
+    if (c->d_all_scratch) (void)hipFree(c->d_all_scratch);
     delete c;
 }
 
@@ -781,6 +783,61 @@ int rrx_search_all_fill(const rrx_regex *re, const rrx_corpus *c, const uint64_t
     int e = dev::search_all(*t, c->d_bytes, c->nbytes, c->d_line_off, c->nlines, nullptr, d_first, d_start, d_end, stream);
     if (e) return hip_fail((hipError_t)e, "search_all launch");
     return RRX_OK;
+}
+
+// count + fill in one call.  Stripe-wise tables: one launch (decoupled look-back over the chunks' match counts).  Otherwise
+// the two passes of the older kernels with a device scan between them.
+int rrx_search_all(const rrx_regex *re, const rrx_corpus *c, uint64_t *d_first, uint32_t *d_start, uint32_t *d_end, size_t cap, size_t *total,
+                   void *stream) {
+    if (!re || !c || !total || !d_first || (cap && (!d_start || !d_end))) return fail(RRX_ERR_ARG, "null argument");
+    *total = 0;
+    const dev::SearchDevice *t;
+    int rc = re->search_tables(c->device, &t);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(c->device));
+    hipStream_t st = (hipStream_t)stream;
+    if (!c->nlines) { HIP_TRY(hipMemsetAsync(d_first, 0, sizeof(uint64_t), st)); HIP_TRY(hipStreamSynchronize(st)); return RRX_OK; }
+    if (const dev::SearchChunkDevice *ct = re->search_chunk_tables(c->device)) {
+        rc = chunk_index(c, stream);
+        if (rc) return rc;
+        const size_t sb = dev::search_all_scratch_bytes(c->nchunks);
+        {
+            std::lock_guard<std::mutex> lock(c->mu);
+            if (!c->d_all_scratch) HIP_TRY(hipMalloc(&c->d_all_scratch, sb));
+        }
+        HIP_TRY(hipMemsetAsync(c->d_all_scratch, 0, sb, st));
+        int e = dev::search_chunks_all(*ct, c->d_bytes, c->nbytes, c->d_chunk_base, c->nchunks, c->nlines, d_first, d_start, d_end, cap,
+                                       c->d_all_scratch, stream);
+        if (e) return hip_fail((hipError_t)e, "search_chunks_all launch");
+        uint64_t tail[2] = {0, 0};                                 // total, {ticket, error flag}
+        HIP_TRY(hipMemcpyAsync(tail, static_cast<uint8_t *>(c->d_all_scratch) + c->nchunks * sizeof(uint64_t), sizeof tail, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (tail[1] >> 32) return fail(RRX_ERR_HIP, "search_all: a chunk's match count was never published (look-back gave up)");
+        *total = (size_t)tail[0];
+        return RRX_OK;
+    }
+    // lane = line kernels: count, scan on the device, fill
+    uint32_t *d_count = nullptr;
+    HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_count), (c->nlines + 1) * sizeof(uint32_t)));
+    uint64_t *d_sums = nullptr;
+    hipError_t he = hipMalloc(reinterpret_cast<void **>(&d_sums), dev::scan_scratch_words(c->nlines) * sizeof(uint64_t));
+    if (he != hipSuccess) { (void)hipFree(d_count); return hip_fail(he, "hipMalloc"); }
+    auto done = [&](int code) { (void)hipFree(d_count); (void)hipFree(d_sums); return code; };
+    rc = rrx_search_all_count(re, c, d_count, stream);
+    if (rc) return done(rc);
+    int e = dev::scan_counts(d_count, d_first, d_sums, c->nlines, stream);      // d_first[nlines] = total
+    if (e) return done(hip_fail((hipError_t)e, "scan launch"));
+    he = hipMemsetAsync(d_first, 0, sizeof(uint64_t), st);                      // the scan marks entry 0 as a stripe start: not here
+    uint64_t tot = 0;
+    if (he == hipSuccess) he = hipMemcpyAsync(&tot, d_first + c->nlines, sizeof tot, hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    if (he != hipSuccess) return done(hip_fail(he, "search_all scan"));
+    *total = (size_t)tot;
+    if (tot && tot <= cap) {
+        rc = rrx_search_all_fill(re, c, d_first, d_start, d_end, stream);
+        if (!rc) { he = hipStreamSynchronize(st); if (he != hipSuccess) rc = hip_fail(he, "search_all fill"); }
+    }
+    return done(rc);
 }
 
 int rrx_bitmap_to_bytes(int device, const uint32_t *d_bits, size_t nlines, uint8_t *d_accept, void *stream) {

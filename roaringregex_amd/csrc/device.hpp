@@ -187,6 +187,12 @@ int search_chunks_count(const SearchChunkDevice &p, const uint8_t *bytes, size_t
                         uint32_t *count, void *stream);
 int search_chunks_fill(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
                        const uint64_t *first, uint32_t *match_start, uint32_t *match_end, void *stream);
+// count and fill in one launch: first[nlines + 1] (CSR offsets of the lines' matches) and the matches themselves, slots
+// >= cap counted but not written; scratch = search_all_scratch_bytes(nchunks), zeroed before the launch, holds the
+// per-chunk status words, then the total (u64), then {ticket, error flag} (u32 each)
+size_t search_all_scratch_bytes(size_t nchunks);
+int search_chunks_all(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks, size_t nlines,
+                      uint64_t *first, uint32_t *match_start, uint32_t *match_end, size_t cap, void *scratch, void *stream);
 size_t search_lds_bytes(const SearchDevice &p);
 // line_off[i] = offset of the first byte of line i (built once per corpus from the stripe index); nlines + 1 entries are
 // the caller's to size, entry nlines is written only when the corpus ends in '\n'.

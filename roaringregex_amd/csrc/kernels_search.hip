@@ -63,17 +63,73 @@ __device__ __forceinline__ size_t reverse_walk(const SearchLds &t, const uint8_t
     return best;
 }
 
-enum { kFirst = 0, kCount = 1, kFill = 2 };
+enum { kFirst = 0, kCount = 1, kFill = 2, kAll = 3 };
+
+// kAll (rrx_search_all): count and fill in ONE launch.  A wave counts the matches of its chunk (the replay of its events
+// and the walk along its last line, nothing written), learns the number of matches in all chunks before its own by a
+// decoupled look-back over per-chunk status words (Merrill & Garland's single-pass scan: every chunk publishes its
+// count, then the sum through itself; a wave sums its predecessors' counts back to the nearest published sum), and
+// replays its events a second time, now placing every match.  Chunks are handed out by a ticket counter, so every chunk
+// before mine belongs to a wave that is already running: the look-back never waits for a wave that has not started.
+struct SearchAllArgs {
+    uint64_t *first_out;        // [nlines + 1] slot of the first match of every line (CSR offsets), written here
+    uint64_t *status;           // [nchunks] zeroed before the launch
+    uint32_t *ticket;           // [0] next chunk, [1] error flag (look-back gave up); zeroed before the launch
+    uint64_t *total;            // number of matches
+    uint64_t cap;               // slots the caller's match arrays hold: matches beyond are counted, not written
+    uint64_t nlines;
+};
+constexpr uint64_t kStAggregate = 1ull << 62, kStInclusive = 2ull << 62, kStFlags = 3ull << 62;
+constexpr uint64_t kLookbackTicks = 10ull * 100000000ull;     // 10 s of the 100 MHz wall clock: a chunk whose first line runs on
+                                                              // for megabytes is counted by ONE lane, and everybody behind waits
+// -> matches in the chunks before `chunk`; publishes `mine` (the chunk's own count) and then the sum through the chunk
+__device__ __forceinline__ uint64_t chunk_lookback(uint64_t *status, uint32_t *ticket, size_t chunk, uint64_t mine, int lane) {
+    if (lane == 0) __hip_atomic_store(&status[chunk], kStAggregate | mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint64_t excl = 0;
+    int64_t pos = (int64_t)chunk;                                 // the window: chunks [pos - 64, pos), lane 0 the nearest
+    uint32_t spins = 0;
+    uint64_t t0 = 0;
+    for (;;) {
+        const int64_t idx = pos - 1 - lane;
+        const uint64_t st = idx >= 0 ? __hip_atomic_load(&status[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kStInclusive;
+        const uint64_t incl = __ballot((st & kStFlags) == kStInclusive);
+        const int first_incl = incl ? __ffsll((long long)incl) - 1 : 64;
+        const uint64_t need = first_incl < 63 ? ((2ull << first_incl) - 1ull) : ~0ull;      // lanes 0 .. first_incl
+        if (__ballot((st & kStFlags) == 0) & need) {              // a chunk on the way has not published yet
+            bool give_up = false;
+            if ((++spins & 255u) == 0) {
+                const uint64_t now = wall_clock64();
+                if (!t0) t0 = now;
+                give_up = now - t0 > kLookbackTicks || __hip_atomic_load(&ticket[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+            }
+            if (give_up) {                                        // never spin for ever: flag the launch as failed and drain
+                if (lane == 0) atomicOr(&ticket[1], 1u);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(4);
+            continue;
+        }
+        uint64_t v = lane <= first_incl ? (st & ~kStFlags) : 0ull;
+#pragma unroll
+        for (int d = 32; d; d >>= 1) v += __shfl_xor(v, d, 64);
+        excl += v;
+        if (first_incl < 64) break;
+        pos -= 64;
+    }
+    if (lane == 0) __hip_atomic_store(&status[chunk], kStInclusive | (excl + mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
 
 // MODE kFirst: match_start/match_end[line] = first match of the line (kNone: no match).
 // MODE kCount: match_start[line] = number of matches of the line (match_end unused).
 // MODE kFill : match_start/match_end[first[line] + k] = k-th match of the line.
+// MODE kAll  : the same, with first[] produced here as well (all.first_out) and the slots bounded by all.cap.
 template <int MODE>
 __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void search_chunks_kernel(SearchChunkDevice prog, const uint8_t *__restrict__ bytes, size_t nbytes,
                                                                           const uint64_t *__restrict__ chunk_base, size_t nchunks,
                                                                           const uint64_t *__restrict__ first,
                                                                           uint32_t *__restrict__ match_start, uint32_t *__restrict__ match_end,
-                                                                          uint32_t kStageLines) {
+                                                                          uint32_t kStageLines, SearchAllArgs all) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // ---- tables into LDS, once per workgroup: its waves then take chunk after chunk (a chunk is only 8 KiB of text, the
     // tables are up to 46 KiB).  The byte -> column table comes first, at LDS address 0, so that 2 * byte IS its address
@@ -84,7 +140,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     uint32_t *R = T + t_words;
     uint32_t *C = R + rev_words;                                  // 64 words
     uint32_t *stage = C + 64;                                     // [wave][kArrays][kStageLines]
-    constexpr uint32_t kArrays = MODE == kFill ? 2 : 1;           // results packed start | end << 16 (kCount: the count); kFill: + slot bases
+    constexpr uint32_t kArrays = (MODE == kFill || MODE == kAll) ? 2 : 1;     // results packed start | end << 16 (kCount: the count); kFill / kAll: + slot bases
     constexpr uint32_t kStageInit = MODE == kCount ? 0u : kNone;  // a line without a match: "none" / zero matches
     if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem != 0u) __builtin_trap();
     const uint32_t t_base = 512u;                                 // LDS address of T
@@ -102,8 +158,16 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t *st_s = stage + (size_t)wave * kArrays * kStageLines;
-    uint32_t *st_f = st_s + kStageLines;                          // kFill: first[line] - first[the wave's first line]
-    for (size_t chunk = (size_t)blockIdx.x * kSearchWaves + wave; chunk < nchunks; chunk += (size_t)gridDim.x * kSearchWaves) {
+    uint32_t *st_f = st_s + kStageLines;                          // kFill / kAll: first[line] - first[the wave's first line]
+    auto next_chunk = [&](size_t prev, bool start) -> size_t {
+        if constexpr (MODE == kAll) {                             // by ticket (see SearchAllArgs)
+            uint32_t tk = 0;
+            if (lane == 0) tk = atomicAdd(&all.ticket[0], 1u);
+            return (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)tk);
+        }
+        return start ? (size_t)blockIdx.x * kSearchWaves + wave : prev + (size_t)gridDim.x * kSearchWaves;
+    };
+    for (size_t chunk = next_chunk(0, true); chunk < nchunks; chunk = next_chunk(chunk, false)) {
     const size_t cstart = chunk * (size_t)kSearchChunk;
     const size_t cend = cstart + kSearchChunk < nbytes ? cstart + kSearchChunk : nbytes;      // end of the chunk's data
     const uint64_t cb = chunk_base[chunk];
@@ -223,28 +287,43 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
         const bool fits = v0 == kNone || v1 < 0xffffu;            // (v0 <= v1)
         if (staged) st_s[idx] = v0 == kNone ? kNone : fits ? (v0 | v1 << 16) : kDirect;
         if (!staged || !fits) {
-            const uint64_t at = (MODE == kFill ? F0 : base_line) + idx;
-            match_start[at] = v0;
-            match_end[at] = v1;
+            const uint64_t at = ((MODE == kFill || MODE == kAll) ? F0 : base_line) + idx;
+            if (MODE != kAll || at < all.cap) { match_start[at] = v0; match_end[at] = v1; }
         }
+    };
+    uint32_t lane_base = 0;                                       // kAll: matches of the lanes before me in this chunk
+    auto set_first = [&](uint32_t line_ord, uint32_t rel) {      // kAll: slot of a line's first match, relative to F0
+        if (line_ord < kStageLines) st_f[line_ord] = rel; else all.first_out[base_line + line_ord] = F0 + rel;
     };
     // ---- 4. the events in byte order, then the rest of my last line beyond my bytes.  A hit whose start is not known QUEUES a job (lower
     // bound, match end, where to put the result, line start): walking back right at the hit would make the lanes of a
     // wave take turns, each waiting through the others' walks (measured: 33 ms for 8 GiB).  Positions are 32-bit
     // offsets from the chunk start from here on.
+    // The whole of step 4 is one pass; kAll runs it twice: counting (nothing written, no walks), then placing.
+    const uint32_t e_fwd = e, ord0 = ord;
+    uint32_t emitted = 0;                                         // kFill / kAll: matches of lines that are mine
+    // kAll: the hits the counting pass meets while following my last line beyond my bytes (position << 2 | flags), so
+    // that the placing pass need not walk that stretch of text again; more than kFollowHits of them: it walks
+    constexpr int kFollowHits = 4;
+    uint32_t fh[kFollowHits];
+    uint32_t nfh = 0;
+    auto run_pass = [&](auto counting_tag) {
+    constexpr bool COUNTING = decltype(counting_tag)::value;
+    e = e_fwd; ord = ord0; emitted = 0;
     constexpr int kJobs = 4;
     uint32_t job_lo[kJobs], job_e[kJobs], job_at[kJobs], job_ls[kJobs];       // slot 0 is the next to run
     uint32_t njobs = 0;
     bool owned = fresh, decided = false;                          // the current line: is it mine; kFirst: has its match been found
+    if constexpr (MODE == kAll && !COUNTING) { if (fresh) set_first(ord0, lane_base); }
     const uint32_t my_rel = (uint32_t)(my - cstart), my_end_rel = (uint32_t)(my_end - cstart);
     uint32_t ls = my_rel;                                         // its first byte (valid if owned)
     uint32_t lb = my_rel;                                         // kFill: a match may not start before here (the previous match's end)
     uint32_t cnt = 0;                                             // kCount / kFill: matches of the current line so far
-    uint32_t emitted = 0;                                         // kFill: matches of lines that are mine
     auto on_hit = [&](uint32_t pos, uint32_t f) {                 // the byte at `pos` completes a match
         if (!owned) return;
         if constexpr (MODE == kCount) { cnt++; return; }
-        const uint32_t at = MODE == kFirst ? ord : slot_base(ord) + cnt;
+        if constexpr (COUNTING) { emitted++; return; }
+        const uint32_t at = MODE == kFirst ? ord : MODE == kAll ? lane_base + emitted : slot_base(ord) + cnt;
         const uint32_t lower = MODE == kFirst ? ls : lb;
         if (f == 3u) emit(at, lower - ls, pos + 1 - ls);          // accepted from the restart point itself: it starts there
         else if (njobs < kJobs) {
@@ -266,6 +345,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
         ls = pos + 1; lb = ls; cnt = 0;
         owned = ls < my_end_rel;                                  // a line that starts at my_end is the next lane's
         decided = false;
+        if constexpr (MODE == kAll && !COUNTING) { if (owned) set_first(ord, lane_base + emitted); }
     };
     // ---- 4a. my events, word by word (a static loop over the event words, a dynamic one over the events of a word: the
     // version with one loop body that rotated the words through ev[0] paid 7 extra turns per lane and a longer body)
@@ -282,6 +362,23 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     }
     // my last line goes on beyond my bytes and is still open (kFirst: undecided): follow it
     int phase = (vlen == kSearchS && last_byte != '\n' && owned && !(MODE == kFirst && decided)) ? 1 : 2;   // 1: following, 2: done
+    auto follow_hit = [&](uint32_t pos, uint32_t f) {
+        if constexpr (MODE == kAll && COUNTING) {
+#pragma unroll
+            for (int j = 0; j < kFollowHits; j++)
+                if ((uint32_t)j == nfh) fh[j] = pos << 2 | f;
+            nfh = pos < (1u << 30) ? nfh + 1 : (uint32_t)kFollowHits + 1;      // (a position that does not fit: walk again)
+        }
+        on_hit(pos, f);
+    };
+    if constexpr (MODE == kAll && !COUNTING) {
+        if (phase == 1 && nfh <= (uint32_t)kFollowHits) {         // the counting pass has been there: its hits, in order
+#pragma unroll
+            for (int j = 0; j < kFollowHits; j++)
+                if ((uint32_t)j < nfh) on_hit(fh[j] >> 2, fh[j] & 3u);
+            phase = 2;
+        }
+    }
     size_t fbyte = my_end;                                        // follow position (word by word while whole 16-byte blocks lie in the data)
     uint4 cur = make_uint4(0, 0, 0, 0), nxt = cur;
     if (phase == 1 && fbyte + 16 <= nbytes) cur = *reinterpret_cast<const uint4 *>(bytes + fbyte);
@@ -316,7 +413,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
                     const uint32_t f = (acc >> (6 - 2 * z)) & 3u;
                     acc &= ~(3u << (6 - 2 * z));
                     if (f == 1u) phase = 2;                       // the line's '\n': done (what lies behind it is not mine)
-                    else { on_hit(wrel + (uint32_t)z, f); if (MODE == kFirst) phase = 2; }
+                    else { follow_hit(wrel + (uint32_t)z, f); if (MODE == kFirst) phase = 2; }
                 }
                 fbyte += 4;
                 if ((fbyte & 15) == 0) cur = nxt;
@@ -324,7 +421,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
                 for (; fbyte < nbytes && phase == 1 && njobs < kJobs; fbyte++) {
                     const uint32_t f = step(e, bytes[fbyte]);
                     if (f == 1u) phase = 2;
-                    else if (f) { on_hit((uint32_t)(fbyte - cstart), f); if (MODE == kFirst) phase = 2; }
+                    else if (f) { follow_hit((uint32_t)(fbyte - cstart), f); if (MODE == kFirst) phase = 2; }
                 }
                 if (fbyte >= nbytes) phase = 2;                   // the end of the data ends the line
             }
@@ -364,6 +461,20 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     // my last line, open to the end of the data (or ended by its '\n' beyond my bytes)
     if constexpr (MODE == kFirst) { if (owned && !decided && ord >= kStageLines) emit(ord, kNone, kNone); }
     if constexpr (MODE == kCount) { if (owned) emit(ord, cnt, 0u); }
+    };      // run_pass
+    uint32_t wave_matches = 0;                                    // kAll: matches of the chunk
+    if constexpr (MODE == kAll) {
+        run_pass(std::true_type{});
+        uint32_t incl_m = emitted;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl_m, d, 64); if (lane >= d) incl_m += o; }
+        wave_matches = __shfl(incl_m, 63, 64);
+        lane_base = incl_m - emitted;
+        F0 = chunk_lookback(all.status, all.ticket, chunk, wave_matches, lane);
+        run_pass(std::false_type{});
+    } else {
+        run_pass(std::false_type{});
+    }
     // ---- 5. write the wave's results: whole sectors, consecutive lanes consecutive entries
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // the staging stores of every lane of this wave are done
     if constexpr (MODE == kFill) {
@@ -375,6 +486,16 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
             const uint32_t v = st_s[j];
             if (v != kDirect) { match_start[F0 + j] = v & 0xffffu; match_end[F0 + j] = v >> 16; }
         }
+    } else if constexpr (MODE == kAll) {
+        const uint32_t staged = wave_matches < kStageLines ? wave_matches : kStageLines;
+        for (uint32_t j = lane; j < staged; j += 64) {
+            const uint32_t v = st_s[j];
+            if (v != kDirect && F0 + j < all.cap) { match_start[F0 + j] = v & 0xffffu; match_end[F0 + j] = v >> 16; }
+        }
+        int64_t hi = hi_ord;
+        if (hi >= (int64_t)kStageLines) hi = (int64_t)kStageLines - 1;
+        for (int64_t j = lo_ord + lane; j <= hi; j += 64) all.first_out[base_line + (uint64_t)j] = F0 + st_f[j];
+        if (cend == nbytes && lane == 0) { all.first_out[all.nlines] = F0 + wave_matches; *all.total = F0 + wave_matches; }
     } else {
         int64_t hi = hi_ord;
         if (hi >= (int64_t)kStageLines) hi = (int64_t)kStageLines - 1;
@@ -401,7 +522,7 @@ static size_t search_table_bytes(const SearchChunkDevice &p) { return ((size_t)p
 // staged entries per wave: what the tables leave of the budget (two workgroups per CU), a multiple of 64, 128 at least
 // (one array of packed results or counts; the fill pass also keeps the lines' slot bases)
 static uint32_t search_stage_lines(const SearchChunkDevice &p, int mode) {
-    const size_t tb = search_table_bytes(p), per = (size_t)kSearchWaves * 4 * (mode == kFill ? 2 : 1);
+    const size_t tb = search_table_bytes(p), per = (size_t)kSearchWaves * 4 * ((mode == kFill || mode == kAll) ? 2 : 1);
     if (tb + per * 128 > kSearchChunkLdsBudget) return 0;
     size_t n = (kSearchChunkLdsBudget - tb) / per;
     n = n / 64 * 64;
@@ -413,11 +534,11 @@ size_t search_chunks_lds_bytes(const SearchChunkDevice &p) {          // of the 
 }
 template <int MODE>
 static int launch_search_chunks(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
-                                const uint64_t *first, uint32_t *out0, uint32_t *out1, void *stream) {
+                                const uint64_t *first, uint32_t *out0, uint32_t *out1, void *stream, SearchAllArgs all = SearchAllArgs()) {
     if (!nchunks) return 0;
     const uint32_t lines = search_stage_lines(p, MODE);
     if (!lines) return (int)hipErrorInvalidValue;
-    const size_t lds = search_table_bytes(p) + (size_t)kSearchWaves * 4 * (MODE == kFill ? 2 : 1) * lines;
+    const size_t lds = search_table_bytes(p) + (size_t)kSearchWaves * 4 * ((MODE == kFill || MODE == kAll) ? 2 : 1) * lines;
     static LdsAttr attr;
     hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(search_chunks_kernel<MODE>), lds);
     if (e != hipSuccess) return (int)e;
@@ -425,7 +546,7 @@ static int launch_search_chunks(const SearchChunkDevice &p, const uint8_t *bytes
     size_t blocks = (nchunks + kSearchWaves - 1) / kSearchWaves;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(search_chunks_kernel<MODE>, dim3((unsigned)blocks), dim3(kSearchWaves * 64), lds, (hipStream_t)stream, p, bytes, nbytes, chunk_base,
-                       nchunks, first, out0, out1, lines);
+                       nchunks, first, out0, out1, lines, all);
     return (int)hipGetLastError();
 }
 int search_chunks(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
@@ -439,6 +560,20 @@ int search_chunks_count(const SearchChunkDevice &p, const uint8_t *bytes, size_t
 int search_chunks_fill(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
                        const uint64_t *first, uint32_t *match_start, uint32_t *match_end, void *stream) {
     return launch_search_chunks<kFill>(p, bytes, nbytes, chunk_base, nchunks, first, match_start, match_end, stream);
+}
+
+// scratch of search_chunks_all: status u64[nchunks] | total u64 | ticket u32[2]; zeroed by the caller before every launch
+size_t search_all_scratch_bytes(size_t nchunks) { return nchunks * sizeof(uint64_t) + 16; }
+int search_chunks_all(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks, size_t nlines,
+                      uint64_t *first, uint32_t *match_start, uint32_t *match_end, size_t cap, void *scratch, void *stream) {
+    SearchAllArgs a;
+    a.first_out = first;
+    a.status = static_cast<uint64_t *>(scratch);
+    a.total = a.status + nchunks;
+    a.ticket = reinterpret_cast<uint32_t *>(a.total + 1);
+    a.cap = cap;
+    a.nlines = nlines;
+    return launch_search_chunks<kAll>(p, bytes, nbytes, chunk_base, nchunks, nullptr, match_start, match_end, stream, a);
 }
 
 }  // namespace dev

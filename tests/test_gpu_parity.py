@@ -690,7 +690,14 @@ def test_search_all_matches_per_line():
     def run(pattern, data):
         dev = torch.from_numpy(np.array(np.frombuffer(data, dtype=np.uint8), copy=True)).cuda()
         r = rr.RRegex(pattern)
-        cnt, first, st, en = r.search_all(rr.Corpus(dev, stripe=1024))
+        corpus = rr.Corpus(dev, stripe=1024)
+        cnt, first, st, en = r.search_all(corpus)
+        # the one-call entry (one pass, decoupled look-back) must give the same CSR arrays, also when the first call's
+        # arrays were too small (cap = 1: counted but not written, then repeated with the exact size)
+        for cap in (None, 1):
+            f2, s2, e2 = r.search_all_fused(corpus, cap=cap)
+            assert f2.numel() == cnt.numel() + 1 and int(f2[-1]) == st.numel(), (pattern, cap)
+            assert torch.equal(f2[:-1], first) and torch.equal(s2, st) and torch.equal(e2, en), (pattern, cap)
         return cnt.cpu().numpy(), first.cpu().numpy(), st.cpu().numpy(), en.cpu().numpy()
 
     for p in pats:
@@ -747,3 +754,28 @@ def test_search_modes_agree_at_scale():
     has = cnt > 0
     assert torch.equal(st[first[has]], s[has]) and torch.equal(en[first[has]], e[has])
     assert int(cnt.sum()) == st.numel()
+    f2, s2, e2 = r.search_all_fused(corpus)
+    assert int(f2[-1]) == st.numel() and torch.equal(f2[:-1], first) and torch.equal(s2, st) and torch.equal(e2, en)
+
+
+def test_search_all_fused_dense_and_long():
+    """rrx_search_all where the staging does not hold a chunk's matches (every byte a match: 16384 per chunk), where a
+    line runs over many chunks (its owner counts and places matches far beyond its own bytes), where offsets do not fit
+    16 bits (lines beyond 64 KiB), and on a corpus without a trailing newline: equal to count + scan + fill."""
+    rng = np.random.default_rng(17)
+    cases = []
+    cases.append(("a", np.full(3 << 20, ord("a"), dtype=np.uint8)))                     # one line, every byte a match
+    d = np.full(2 << 20, ord("a"), dtype=np.uint8); d[rng.integers(0, d.size, 300)] = 10
+    cases.append(("a", d))                                                               # long lines of matches
+    d = rng.choice(np.frombuffer(b"ab \n", dtype=np.uint8), size=4 << 20, p=[0.45, 0.45, 0.09, 0.01]).astype(np.uint8)
+    cases.append(("ab+", d))
+    d = rng.choice(np.frombuffer(b"abc", dtype=np.uint8), size=1 << 20).astype(np.uint8); d[200000] = 10; d[900000] = 10
+    cases.append(("a{1,300}b", d))                                                       # three lines of > 64 KiB
+    for pattern, data in cases:
+        dev = torch.from_numpy(data).cuda()
+        corpus = rr.Corpus(dev)
+        r = rr.RRegex(pattern)
+        cnt, first, st, en = r.search_all(corpus)
+        f2, s2, e2 = r.search_all_fused(corpus)
+        assert int(f2[-1]) == st.numel(), pattern
+        assert torch.equal(f2[:-1], first) and torch.equal(s2, st) and torch.equal(e2, en), pattern
