@@ -142,6 +142,15 @@ public:
         auto *f = static_cast<DeviceIterFactory *>(iter_factory.get());
         if (rrx_search_corpus(f->handle(), corpus, d_start, d_end, stream) != RRX_OK) throw std::runtime_error(rrx_last_error());
     }
+    // every lazy match of every string, left to right, in one call (rrx_search_all): d_first[i] (nlines + 1 entries) = slot
+    // of string i's first match; returns the number of matches - if it exceeds `cap` (the entries d_start / d_end hold),
+    // those beyond were not written: call again with arrays of that size.  Synchronous.
+    size_t search_all(const rrx_corpus *corpus, uint64_t *d_first, uint32_t *d_start, uint32_t *d_end, size_t cap, void *stream = nullptr) {
+        auto *f = static_cast<DeviceIterFactory *>(iter_factory.get());
+        size_t total = 0;
+        if (rrx_search_all(f->handle(), corpus, d_first, d_start, d_end, cap, &total, stream) != RRX_OK) throw std::runtime_error(rrx_last_error());
+        return total;
+    }
 };
 
 }  // namespace Regex
