@@ -349,6 +349,13 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     };
     // ---- 4a. my events, word by word (a static loop over the event words, a dynamic one over the events of a word: the
     // version with one loop body that rotated the words through ev[0] paid 7 extra turns per lane and a longer body)
+    if constexpr (MODE == kAll && COUNTING) {
+        // counting needs no replay: every hit among my events is mine (a lane that begins inside a line sits in the SKIP
+        // row until its first '\n', so it records no hit for that line), and my last line is mine if any line starts here
+#pragma unroll
+        for (int i = 0; i < kEv; i++) emitted += __popc(ev[i] & 0xaaaaaaaau);
+        owned = fresh || nl > 0;
+    } else {
 #pragma unroll
     for (int i = 0; i < kEv; i++) {
         uint32_t m = ev[i];
@@ -359,6 +366,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
             const uint32_t pos = my_rel + (uint32_t)(16 * i + z);
             if (f == 1u) on_newline(pos); else on_hit(pos, f);
         }
+    }
     }
     // my last line goes on beyond my bytes and is still open (kFirst: undecided): follow it
     int phase = (vlen == kSearchS && last_byte != '\n' && owned && !(MODE == kFirst && decided)) ? 1 : 2;   // 1: following, 2: done
