@@ -93,6 +93,23 @@ while done < npat:
                 print("MISMATCH search", repr(p), "mix", mix, "line", int(bad[0]), (int(gs[bad[0]]), int(ge[bad[0]])), "want", (int(st[bad[0]]), int(en[bad[0]])), flush=True)
                 sys.exit(1)
             checked += 1
+    # all matches: the one-launch entry (rrx_search_all, look-back over the chunks) against count + prefix sum + fill, on
+    # every corpus mix (long lines cross many chunks; cap 1 forces the second call)
+    if len(arr):
+        try:
+            corpus = rr.Corpus(dev)
+            cnt, first, ms, me = engines[0].search_all(corpus)
+        except rr.RRegexError as err:
+            assert "too large" in str(err)
+            cnt = None
+        if cnt is not None:
+            for cap in (None, 1):
+                f2, s2, e2 = engines[0].search_all_fused(corpus, cap=cap)
+                ok = int(f2[-1]) == ms.numel() and torch.equal(f2[:-1], first) and torch.equal(s2, ms) and torch.equal(e2, me)
+                if not ok:
+                    print("MISMATCH search_all", repr(p), "mix", mix, "cap", cap, "matches", int(ms.numel()), int(f2[-1]), flush=True)
+                    sys.exit(1)
+                checked += 1
     done += 1
     if done % 20 == 0:
         print("patterns", done, "checks", checked, "%.0f s" % (time.time() - t0), flush=True)
