@@ -347,6 +347,47 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
         decided = false;
         if constexpr (MODE == kAll && !COUNTING) { if (owned) set_first(ord, lane_base + emitted); }
     };
+    // ---- walks back: every lane that has a queued job takes its oldest one; then ONE tight loop steps all of them (a
+    // reverse step per turn: text re-read from L1/L2 four bytes per load, the next word requested a word ahead) until the
+    // longest is done; then the lanes emit.  (The first version ran pop, step and emit in one loop body, each under its own
+    // lane mask - every turn paid for all three, 80 instructions for one reverse step - and a lane whose queue was full
+    // walked alone inside the event loop: 56 % of the first-match search on the email config.)  Positions are offsets
+    // from the chunk start.
+    const uint8_t *const cbase = bytes + cstart;
+    auto drain = [&]() {
+        while (__ballot(njobs != 0)) {
+            const bool have = njobs != 0;
+            uint32_t lo = 0, e_rel = 0, cur_at = 0, cur_ls = 0, k = 0, best = 0, r = 0, w = 0, wn = 0;
+            if (have) {
+                lo = job_lo[0]; e_rel = job_e[0]; cur_at = job_at[0]; cur_ls = job_ls[0];
+#pragma unroll
+                for (int j = 0; j + 1 < kJobs; j++) { job_lo[j] = job_lo[j + 1]; job_e[j] = job_e[j + 1]; job_at[j] = job_at[j + 1]; job_ls[j] = job_ls[j + 1]; }
+                njobs--;
+                k = e_rel; best = e_rel; r = t.start_r;
+                const uint32_t a0 = (k - 1u) & ~3u;               // e_rel > lo: a match is never empty here
+                wn = *reinterpret_cast<const uint32_t *>(cbase + a0);
+                w = wn;
+                if (a0 >= 4u && a0 > lo) wn = *reinterpret_cast<const uint32_t *>(cbase + a0 - 4u);
+            }
+            bool active = have;
+            while (__ballot(active)) {
+                if (active) {
+                    k--;
+                    const uint32_t c = (w >> (8u * (k & 3u))) & 0xffu;
+                    const uint32_t x = t.rev[r * t.K + t.cls[c]];
+                    r = x & 0x7fffu;
+                    if (r && (x & 0x8000u)) best = k;
+                    if (!r || k == lo) active = false;            // dead, or at the lower bound: done
+                    else if ((k & 3u) == 0) {                     // the next byte down lies in the word below
+                        w = wn;
+                        if (k >= 8u && k - 4u > lo) wn = *reinterpret_cast<const uint32_t *>(cbase + k - 8u);
+                    }
+                }
+            }
+            if (have) emit(cur_at, best - cur_ls, e_rel - cur_ls);
+        }
+    };
+    constexpr bool kWalks = !COUNTING && MODE != kCount;          // this pass queues jobs
     // ---- 4a. my events, word by word (a static loop over the event words, a dynamic one over the events of a word: the
     // version with one loop body that rotated the words through ev[0] paid 7 extra turns per lane and a longer body)
     if constexpr (MODE == kAll && COUNTING) {
@@ -434,37 +475,8 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
                 if (fbyte >= nbytes) phase = 2;                   // the end of the data ends the line
             }
         }
-        // ---- 4c. walk back from every queued match end to its lower bound with the reverse table: smallest start.  Every
-        // lane runs through its own jobs back to back, one reverse step per turn of the loop (text re-read from L1/L2,
-        // four bytes per load, the next word requested one word ahead).
-        bool active = false;
-        size_t k = 0, lo = 0, best = 0, e_abs = 0;
-        uint32_t r = 0, w = 0, wn = 0, cur_at = 0, cur_ls = 0;
-        while (active || njobs) {
-            if (!active) {
-                lo = cstart + job_lo[0]; e_abs = cstart + job_e[0]; cur_at = job_at[0]; cur_ls = job_ls[0];
-#pragma unroll
-                for (int j = 0; j + 1 < kJobs; j++) { job_lo[j] = job_lo[j + 1]; job_e[j] = job_e[j + 1]; job_at[j] = job_at[j + 1]; job_ls[j] = job_ls[j + 1]; }
-                njobs--;
-                k = e_abs; best = e_abs; r = t.start_r; active = true;
-                const size_t a0 = (k - 1) & ~(size_t)3;           // e_abs > lo: a match is never empty here
-                wn = *reinterpret_cast<const uint32_t *>(bytes + a0);
-                w = wn;
-                if (a0 >= 4 && a0 > lo) wn = *reinterpret_cast<const uint32_t *>(bytes + a0 - 4);
-            }
-            k--;
-            const uint32_t c = (w >> (8 * (k & 3))) & 0xffu;
-            const uint32_t x = t.rev[r * t.K + t.cls[c]];
-            r = x & 0x7fffu;
-            if (r && (x & 0x8000u)) best = k;
-            if (!r || k == lo) {                                  // dead, or at the lower bound: the job is done
-                emit(cur_at, (uint32_t)(best - cstart) - cur_ls, (uint32_t)(e_abs - cstart) - cur_ls);
-                active = false;
-            } else if ((k & 3) == 0) {                            // the next byte down lies in the word below
-                w = wn;
-                if (k >= 8 && k - 4 > lo) wn = *reinterpret_cast<const uint32_t *>(bytes + k - 8);
-            }
-        }
+        // ---- 4c. the queued walks
+        if constexpr (kWalks) drain();
     }
     // my last line, open to the end of the data (or ended by its '\n' beyond my bytes)
     if constexpr (MODE == kFirst) { if (owned && !decided && ord >= kStageLines) emit(ord, kNone, kNone); }
