@@ -301,6 +301,12 @@ __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t 
 #pragma unroll
         for (int i = 0; i < kSlots; i++) buf[i] = load_text(src + i);
     }
+    // The line that straddles my stripe end is followed into the next stripe's text (below).  Its first 128 bytes are
+    // requested while the last round is still being stepped: loaded on demand, 16 bytes at a time, they were a chain of
+    // L2 round trips at the end of every wave's life, and the waves of a workgroup - of the whole chip, launched together
+    // and fed at the same rate - reach that point at the same time.
+    uint32_t last_word = 0;                                       // the last text word of my stripe (whole rounds only)
+    bool ahead = false;                                           // buf holds the 128 bytes behind my stripe
     for (int r = 0; r < rounds; r++) {
 #pragma unroll
         for (int i = 0; i < kSlots; i++) {
@@ -326,6 +332,13 @@ __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t 
         if (r + 1 < rounds) {
 #pragma unroll
             for (int i = 0; i < kSlots; i++) buf[i] = load_text(src + (r + 1) * kSlots + i);
+        } else {
+            last_word = buf[kSlots - 1].w;
+            if (start + (size_t)(rounds + 1) * kRound <= nbytes) {
+#pragma unroll
+                for (int i = 0; i < kSlots; i++) buf[i] = load_text(src + (r + 1) * kSlots + i);
+                ahead = true;
+            }
         }
     }
     pos += (size_t)rounds * kRound;
@@ -357,8 +370,22 @@ __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t 
     if (ONEPASS && res.seen == 0) fresh = g == 0 || bytes[start - 1] == '\n';   // a stripe without any '\n': whose line is it?
     const bool started = fresh || res.seen > 0;
     bool followed = false;
-    if (!closed_by_end_of_data && started && bytes[my_end - 1] != '\n') {
+    const bool whole_rounds = rounds > 0 && start + (size_t)rounds * kRound == my_end;
+    const uint32_t last_byte = whole_rounds ? last_word >> 24 : (uint32_t)bytes[my_end - 1];
+    if (!closed_by_end_of_data && started && last_byte != '\n') {
         uint32_t lines = 0, verdicts = 0;
+        if (ahead && pos == start + (size_t)(rounds + 1) * kRound - kRound) {      // (pos == my_end: the requested bytes are the next ones)
+#pragma unroll
+            for (int i = 0; i < kSlots; i++) {
+                if (!lines) {
+                    const uint32_t w[4] = {clean(buf[i].x), clean(buf[i].y), clean(buf[i].z), clean(buf[i].w)};
+#pragma unroll
+                    for (int k = 0; k < 8; k++)
+                        if (!lines) eng.step2(st, (w[k >> 1] >> (16 * (k & 1))) & 0xffu, (w[k >> 1] >> (16 * (k & 1) + 8)) & 0xffu, lines, verdicts);
+                    pos += 16;
+                }
+            }
+        }
         while (pos + 16 <= nbytes && !lines) {
             const uint4 v = *reinterpret_cast<const uint4 *>(bytes + pos);
             const uint32_t w[4] = {clean(v.x), clean(v.y), clean(v.z), clean(v.w)};
@@ -374,7 +401,7 @@ __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t 
     }
     res.finish();
     if (ONEPASS)
-        counts[g] = newlines | ((followed || closed_by_end_of_data) ? kExtraResult : 0u) | (bytes[my_end - 1] == '\n' ? kEndsOnNewline : 0u);
+        counts[g] = newlines | ((followed || closed_by_end_of_data) ? kExtraResult : 0u) | (last_byte == '\n' ? kEndsOnNewline : 0u);
     }
     if (!ONEPASS) {
         // ---- write the window out: consecutive lanes, consecutive words (the atomics merge into whole lines in L2;
