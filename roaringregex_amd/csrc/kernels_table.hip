@@ -791,23 +791,26 @@ __global__ __launch_bounds__(256) void search_all_kernel(SearchDevice prog, cons
 // Chunk maps.  LDS: the plain DFA widened to one u16 entry per (state, byte value 0..127 | >= 0x80), entry = row
 // offset of the next state (state * 129), so a step is one clamp, one add and one ds_read_u16.
 constexpr int kLongThreads = 256;
-__global__ __launch_bounds__(kLongThreads) void long_maps_kernel(DfaDevice p, const uint8_t *__restrict__ bytes, size_t nbytes, uint32_t chunk,
-                                                                 uint32_t nchunks, uint16_t *__restrict__ maps) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint16_t *wide = reinterpret_cast<uint16_t *>(smem);
+//
+// Convergence (round 2): stepping a chunk from EVERY state costs D times the text.  But a DFA forgets where it started:
+// after a few dozen bytes the D runs of a chunk sit in one, two, three different states (a whole-string match against
+// running text is dead almost at once).  So the chunk maps are built in four steps:
+//   A  long_maps_kernel with limit = kLongPrefix: the state after the chunk's first 64 bytes, from every state;
+//   B  long_continue_kernel: lane = (chunk, slot j < kLongSlots): the j-th DISTINCT state among those D, stepped through
+//      the rest of the chunk - 4 lanes per chunk instead of D; a chunk with more distinct states is flagged;
+//   A' long_maps_kernel with limit = chunk for the flagged chunks only (the old way: automata that count, a{1,200} on a's);
+//   C  long_expand_kernel: map[s] = result of the slot that holds prefix_state[s].
+constexpr uint32_t kLongPrefix = 64, kLongSlots = 4;
+__device__ __forceinline__ void long_load_wide(const DfaDevice &p, uint16_t *wide) {
     const uint32_t D = p.nstates;
-    for (uint32_t i = threadIdx.x; i < D * kWideColumns; i += kLongThreads) {
+    for (uint32_t i = threadIdx.x; i < D * kWideColumns; i += blockDim.x) {
         const uint32_t s = i / kWideColumns, c = i % kWideColumns;
         wide[i] = (uint16_t)(p.next[s * p.ncls + p.cls[c]] * kWideColumns);     // column 128 stands for every byte >= 0x80
     }
-    __syncthreads();
-    const uint32_t per_block = kLongThreads / D, ci = threadIdx.x / D, s0 = threadIdx.x % D;
-    const size_t k = (size_t)blockIdx.x * per_block + ci;
-    if (ci >= per_block || k >= nchunks) return;
-    const size_t a = k * (size_t)chunk, b = a + chunk < nbytes ? a + chunk : nbytes;
-    uint32_t row = s0 * kWideColumns;
-    size_t pos = a;
-    if ((reinterpret_cast<uintptr_t>(bytes) & 15) == 0) {                       // chunk starts are multiples of 16
+}
+// the row after bytes [pos, b) from `row` (pos 16-byte aligned if the base pointer is)
+__device__ __forceinline__ uint32_t long_walk(const uint16_t *wide, const uint8_t *__restrict__ bytes, size_t pos, size_t b, uint32_t row) {
+    if ((reinterpret_cast<uintptr_t>(bytes + pos) & 15) == 0) {
         for (; pos + 16 <= b; pos += 16) {
             const uint4 v = *reinterpret_cast<const uint4 *>(bytes + pos);
             const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -822,16 +825,103 @@ __global__ __launch_bounds__(kLongThreads) void long_maps_kernel(DfaDevice p, co
         const uint32_t c = bytes[pos];
         row = wide[row + (c < 128 ? c : 128)];
     }
-    maps[k * D + s0] = (uint16_t)(row / kWideColumns);
+    return row;
 }
-// out[g] = in[g*group + group-1] o ... o in[g*group]   (one lane per start state; dependent L2 reads)
+// maps[k][s] = state after the first `limit` bytes of chunk k from state s; with `only`: just the chunks flagged there
+__global__ __launch_bounds__(kLongThreads) void long_maps_kernel(DfaDevice p, const uint8_t *__restrict__ bytes, size_t nbytes, uint32_t chunk,
+                                                                 uint32_t nchunks, uint16_t *__restrict__ maps, uint32_t limit,
+                                                                 const uint8_t *__restrict__ only) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t *wide = reinterpret_cast<uint16_t *>(smem);
+    const uint32_t D = p.nstates;
+    const uint32_t per_block = kLongThreads / D, ci = threadIdx.x / D, s0 = threadIdx.x % D;
+    // the workgroups take batch after batch of per_block chunks: the table (D * 129 entries, two dependent loads and a
+    // division each) is built once per workgroup, not once per batch
+    bool loaded = false;
+    for (size_t k0 = (size_t)blockIdx.x * per_block; k0 < nchunks; k0 += (size_t)gridDim.x * per_block) {
+        const size_t k = k0 + ci;
+        const bool mine = ci < per_block && k < nchunks && (!only || only[k]);
+        if (only && !__syncthreads_or(mine ? 1 : 0)) continue;       // nothing flagged in this batch
+        if (!loaded) { long_load_wide(p, wide); __syncthreads(); loaded = true; }
+        if (!mine) continue;
+        const size_t a = k * (size_t)chunk;
+        size_t b = a + chunk < nbytes ? a + chunk : nbytes;
+        if (a + limit < b) b = a + limit;
+        maps[k * D + s0] = (uint16_t)(long_walk(wide, bytes, a, b, s0 * kWideColumns) / kWideColumns);
+    }
+}
+// B: lane = (chunk, slot).  pre[k][*] = the D prefix states of chunk k (step A).  dist[k][j] = j-th distinct one (0xffff: none),
+// res[k][j] = the state it reaches at the end of the chunk; flags[k] = 1 if there are more than kLongSlots.
+__global__ __launch_bounds__(kLongThreads) void long_continue_kernel(DfaDevice p, const uint8_t *__restrict__ bytes, size_t nbytes, uint32_t chunk,
+                                                                     uint32_t nchunks, const uint16_t *__restrict__ pre, uint16_t *__restrict__ dist,
+                                                                     uint16_t *__restrict__ res, uint8_t *__restrict__ flags) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t *wide = reinterpret_cast<uint16_t *>(smem);
+    const uint32_t D = p.nstates;
+    long_load_wide(p, wide);
+    __syncthreads();
+    const size_t lane = (size_t)blockIdx.x * kLongThreads + threadIdx.x;
+    const size_t k = lane / kLongSlots;
+    const uint32_t j = (uint32_t)(lane % kLongSlots);
+    if (k >= nchunks) return;
+    uint32_t list[kLongSlots];
+    uint32_t cnt = 0;                                                // distinct prefix states seen, in order of first appearance
+#pragma unroll
+    for (uint32_t i = 0; i < kLongSlots; i++) list[i] = 0xffffu;
+    for (uint32_t s = 0; s < D && cnt <= kLongSlots; s++) {
+        const uint32_t v = pre[k * D + s];
+        bool seen = false;
+#pragma unroll
+        for (uint32_t i = 0; i < kLongSlots; i++) seen |= i < cnt && list[i] == v;
+        if (!seen) {
+#pragma unroll
+            for (uint32_t i = 0; i < kLongSlots; i++)
+                if (i == cnt) list[i] = v;
+            cnt++;
+        }
+    }
+    if (cnt > kLongSlots) { if (j == 0) flags[k] = 1; return; }
+    uint32_t mine = 0xffffu;
+#pragma unroll
+    for (uint32_t i = 0; i < kLongSlots; i++)
+        if (i == j) mine = list[i];
+    dist[k * kLongSlots + j] = (uint16_t)mine;
+    if (j == 0) flags[k] = 0;
+    if (mine == 0xffffu) return;
+    const size_t a = k * (size_t)chunk, b = a + chunk < nbytes ? a + chunk : nbytes;
+    const size_t from = a + kLongPrefix < b ? a + kLongPrefix : b;
+    res[k * kLongSlots + j] = (uint16_t)(long_walk(wide, bytes, from, b, mine * kWideColumns) / kWideColumns);
+}
+// C: lane = (chunk, state), in place: maps[k][s] holds the prefix state and receives the chunk's map entry
+__global__ __launch_bounds__(kLongThreads) void long_expand_kernel(uint16_t *__restrict__ maps, uint32_t D, uint32_t nchunks,
+                                                                   const uint16_t *__restrict__ dist, const uint16_t *__restrict__ res,
+                                                                   const uint8_t *__restrict__ flags) {
+    const size_t i = (size_t)blockIdx.x * kLongThreads + threadIdx.x;
+    if (i >= (size_t)nchunks * D) return;
+    const size_t k = i / D;
+    if (flags[k]) return;                                            // built the old way (step A')
+    const uint32_t v = maps[i];
+    uint32_t out = 0;
+#pragma unroll
+    for (uint32_t j = 0; j < kLongSlots; j++)
+        if (dist[k * kLongSlots + j] == v) out = res[k * kLongSlots + j];
+    maps[i] = (uint16_t)out;
+}
+// out[g] = in[g*group + group-1] o ... o in[g*group]   (one lane per start state).  The group's maps are copied into LDS
+// first (coalesced) and composed from there: composing straight from HBM/L2 was `group` dependent round trips per level,
+// 90 us for 128, and three levels were most of the time of a string of a few MiB.
 __global__ __launch_bounds__(kLongThreads) void long_compose_kernel(const uint16_t *__restrict__ in, uint32_t nin, uint32_t D, uint32_t group,
                                                                     uint16_t *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint16_t *sm = reinterpret_cast<uint16_t *>(smem);
+    const size_t lo = (size_t)blockIdx.x * group, hi = lo + group < nin ? lo + group : nin;
+    const uint32_t cnt = (uint32_t)(hi - lo);
+    for (uint32_t i = threadIdx.x; i < cnt * D; i += kLongThreads) sm[i] = in[lo * D + i];
+    __syncthreads();
     const uint32_t j = threadIdx.x;
     if (j >= D) return;
-    const size_t lo = (size_t)blockIdx.x * group, hi = lo + group < nin ? lo + group : nin;
     uint32_t s = j;
-    for (size_t k = lo; k < hi; k++) s = in[k * D + s];
+    for (uint32_t k = 0; k < cnt; k++) s = sm[k * D + s];
     out[(size_t)blockIdx.x * D + j] = (uint16_t)s;
 }
 __global__ void long_finish_kernel(const uint16_t *__restrict__ map, DfaDevice p, uint8_t *__restrict__ accept) {
@@ -955,7 +1045,9 @@ static uint32_t long_chunk(size_t nbytes) {
 size_t long_scratch_bytes(uint32_t nstates, size_t nbytes, uint32_t *chunk) {
     *chunk = long_chunk(nbytes);
     const size_t k0 = (nbytes + *chunk - 1) / *chunk, k1 = (k0 + kLongGroup - 1) / kLongGroup;
-    return (k0 + k1 + 2) * nstates * sizeof(uint16_t);         // level 0, then the levels ping-pong between two areas
+    // level 0, then the levels ping-pong between two areas; then per chunk kLongSlots distinct prefix states and their
+    // results (u16 each) and a flag byte
+    return (k0 + k1 + 2) * nstates * sizeof(uint16_t) + k0 * (kLongSlots * 2 * sizeof(uint16_t) + 1) + 16;
 }
 int match_long_dfa(const DfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t chunk, void *scratch, uint8_t *accept,
                    void *stream) {
@@ -965,16 +1057,34 @@ int match_long_dfa(const DfaDevice &p, const uint8_t *bytes, size_t nbytes, uint
     static LdsAttr attr;
     hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(long_maps_kernel), lds);
     if (e != hipSuccess) return (int)e;
+    static LdsAttr attr2, attr3;
+    e = ensure_dynamic_lds(attr2, reinterpret_cast<const void *>(long_continue_kernel), lds);
+    if (e == hipSuccess) e = ensure_dynamic_lds(attr3, reinterpret_cast<const void *>(long_compose_kernel), (size_t)kLongGroup * D * sizeof(uint16_t));
+    if (e != hipSuccess) return (int)e;
     uint32_t n = (uint32_t)((nbytes + chunk - 1) / chunk);
     uint16_t *cur = static_cast<uint16_t *>(scratch), *other = cur + (size_t)n * D;
+    const size_t k1 = ((size_t)n + kLongGroup - 1) / kLongGroup;
+    uint16_t *dist = cur + ((size_t)n + k1 + 2) * D, *res = dist + (size_t)n * kLongSlots;
+    uint8_t *flags = reinterpret_cast<uint8_t *>(res + (size_t)n * kLongSlots);
     const uint32_t per_block = kLongThreads / D;
-    hipLaunchKernelGGL(long_maps_kernel, dim3((n + per_block - 1) / per_block), dim3(kLongThreads), lds, (hipStream_t)stream, p, bytes, nbytes,
-                       chunk, n, cur);
+    const uint32_t batches = (n + per_block - 1) / per_block;
+    const dim3 by_state(batches < 2048 ? batches : 2048);
+    hipStream_t st = (hipStream_t)stream;
+    if (chunk > 2 * kLongPrefix) {
+        hipLaunchKernelGGL(long_maps_kernel, by_state, dim3(kLongThreads), lds, st, p, bytes, nbytes, chunk, n, cur, kLongPrefix, nullptr);
+        hipLaunchKernelGGL(long_continue_kernel, dim3((unsigned)(((size_t)n * kLongSlots + kLongThreads - 1) / kLongThreads)), dim3(kLongThreads), lds, st, p,
+                           bytes, nbytes, chunk, n, cur, dist, res, flags);
+        hipLaunchKernelGGL(long_maps_kernel, by_state, dim3(kLongThreads), lds, st, p, bytes, nbytes, chunk, n, cur, chunk, flags);
+        hipLaunchKernelGGL(long_expand_kernel, dim3((unsigned)(((size_t)n * D + kLongThreads - 1) / kLongThreads)), dim3(kLongThreads), 0, st, cur, D, n, dist, res,
+                           flags);
+    } else {
+        hipLaunchKernelGGL(long_maps_kernel, by_state, dim3(kLongThreads), lds, st, p, bytes, nbytes, chunk, n, cur, chunk, nullptr);
+    }
     uint16_t *area[2] = {other, cur};                          // level 1 writes behind level 0, level 2 over level 0, ...
     for (int lvl = 0; n > 1; lvl++) {
         const uint32_t m = (n + kLongGroup - 1) / kLongGroup;
         uint16_t *dst = area[lvl & 1];
-        hipLaunchKernelGGL(long_compose_kernel, dim3(m), dim3(kLongThreads), 0, (hipStream_t)stream, cur, n, D, kLongGroup, dst);
+        hipLaunchKernelGGL(long_compose_kernel, dim3(m), dim3(kLongThreads), (size_t)kLongGroup * D * sizeof(uint16_t), (hipStream_t)stream, cur, n, D, kLongGroup, dst);
         cur = dst;
         n = m;
     }

@@ -589,6 +589,11 @@ def test_one_long_string_is_stepped_in_parallel_chunks():
     cases.append((".*abc.*", high))
     url = np.frombuffer(b"https://www.example.com/" + b"a/b-c_d.e" * 30000 + b"?q=1", dtype=np.uint8)
     cases += [(U2, url), (U2, url[:-4]), (U2, np.concatenate([url, np.frombuffer(b" x", dtype=np.uint8)]))]
+    # an automaton that counts does not forget where it started: the chunks keep more distinct states than the
+    # convergence path has slots and fall back to stepping every state through the whole chunk
+    runs = np.frombuffer((b"a" * 37 + b"b") * 2500, dtype=np.uint8)
+    broken = runs.copy(); broken[50_000:50_120] = ord("a")
+    cases += [("(a{1,100}b)*", runs), ("(a{1,100}b)*", broken), ("(a{1,100}b)*", runs[:-1])]
     oracles = {}
     for pattern, t in cases:
         o = oracles.setdefault(pattern, OracleRegex(pattern))
