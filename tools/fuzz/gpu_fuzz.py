@@ -110,6 +110,23 @@ while done < npat:
                     print("MISMATCH search_all", repr(p), "mix", mix, "cap", cap, "matches", int(ms.numel()), int(f2[-1]), flush=True)
                     sys.exit(1)
                 checked += 1
+    # ONE long string (rrx_match_string: chunk maps by convergence on the table engine, chunk relations on the NFA engine)
+    # against the oracle: random text, and an accepted line repeated (accepted as a whole by starred patterns)
+    if done % 3 == 0:
+        texts = [np.frombuffer("".join(rng.choice("abcxk01.d") for _ in range(rng.choice([33000, 70001, 150000]))).encode(), dtype=np.uint8)]
+        hits = [ln for ln, w in zip(data.split(b"\n"), want) if w and 0 < len(ln) < 64]
+        if hits:
+            texts.append(np.frombuffer(hits[0] * (40000 // len(hits[0]) + 1), dtype=np.uint8))
+        for t in texts:
+            wl = o.accepts(t.tobytes())
+            td = torch.from_numpy(t.copy()).cuda()
+            for r_ in engines:
+                if r_.engine_name.startswith("nfa-group") or r_.engine_name.startswith("nfa-block"):
+                    continue                               # (a lane group / a workgroup per string: minutes on long strings)
+                if r_.match_string(td) != wl:
+                    print("MISMATCH long string", repr(p), r_.engine_name, len(t), "want", wl, flush=True)
+                    sys.exit(1)
+                checked += 1
     done += 1
     if done % 20 == 0:
         print("patterns", done, "checks", checked, "%.0f s" % (time.time() - t0), flush=True)
