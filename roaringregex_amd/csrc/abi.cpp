@@ -37,6 +37,12 @@ struct DeviceTables {
     dev::BlockNfaDevice block;   // block-cooperative NFA (up to 65536 positions)
 };
 
+// The plain table in the wide line-table format with one more column: 0..127 byte values ('\n' an ordinary byte), 128 =
+// any byte >= 0x80, 129 = END OF ITEM (verdict of the row, back to the start row).  For explicit items stepped stripe-wise.
+struct ItemsTableOnDevice {
+    void *blob = nullptr;
+    dev::LineDfaDevice line;
+};
 struct SearchTablesOnDevice {
     void *blob = nullptr;
     dev::SearchDevice dev;
@@ -70,6 +76,7 @@ struct rrx_regex {
     mutable DfaProgram search_fwd, search_rev;
     mutable SearchLineProgram search_line;  // stripe-wise form (nrows = 0: not built)
     mutable std::map<int, SearchTablesOnDevice> search_on_device;
+    mutable std::map<int, ItemsTableOnDevice> items_on_device;
     // Scratch of the single-string entries (rrx_match_string / rrx_match_cstr): one grow-only device buffer per device,
     // kept across calls (a hipMalloc + hipFree pair per string cost more than the match itself).  `scratch_mu` is held
     // for the whole call: those entries are synchronous, concurrent callers of one regex take turns.
@@ -109,6 +116,38 @@ struct rrx_regex {
         for (auto &kv : onepass_scratch) if (kv.second.p) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.p); }
         for (auto &kv : on_device) if (kv.second.blob) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.blob); }
         for (auto &kv : search_on_device) if (kv.second.blob) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.blob); }
+        for (auto &kv : items_on_device) if (kv.second.blob) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.blob); }
+    }
+    // nullptr: the plain table has too many states for 16-bit row offsets (or there is none)
+    const dev::LineDfaDevice *items_table(int device) const {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = items_on_device.find(device);
+        if (it != items_on_device.end()) return it->second.blob ? &it->second.line : nullptr;
+        ItemsTableOnDevice t;
+        // rows of kItemColumns entries (odd: a column's entries of different rows spread over all LDS banks), R interleaved
+        // copies like the wide line table (lane l reads copy l % R: only banks congruent to l mod R)
+        const uint32_t D = dfa.nstates, stride = dev::kItemColumns;
+        uint32_t rep = 0;
+        while (rep < 3 && (size_t)D * stride * 4 * (2u << rep) <= 60 * 1024) rep++;
+        const uint32_t R = 1u << rep, row_bytes = stride * 4 * R;
+        if (D && (size_t)D * row_bytes <= 65535 && hipSetDevice(device) == hipSuccess) {
+            std::vector<uint32_t> T((size_t)D * stride * R, 0);
+            for (uint32_t q = 0; q < D; q++)
+                for (uint32_t c = 0; c < stride; c++) {
+                    uint32_t v;
+                    if (c <= 128) v = (uint32_t)dfa.next[(size_t)q * dfa.ncls + dfa.cls[c]] * row_bytes;
+                    else if (c == dev::kItemEndColumn) v = dfa.start * row_bytes | 1u << 16 | (dfa.accepting[q] ? 1u << 24 : 0u);
+                    else v = 0;                                                          // padding column: never read
+                    for (uint32_t k = 0; k < R; k++) T[((size_t)q * stride + c) * R + k] = (v & 0xffff0000u) | ((v & 0xffffu) + 4 * k);
+                }
+            if (hipMalloc(&t.blob, T.size() * 4 + 16) == hipSuccess) {
+                if (hipMemcpy(t.blob, T.data(), T.size() * 4, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(t.blob); t.blob = nullptr; }
+            }
+            t.line.nrows = D; t.line.stride = stride * R; t.line.start_off = dfa.start * row_bytes; t.line.wide = 1; t.line.rep_log2 = rep; t.line.in_global = 0;
+            t.line.table = static_cast<const uint32_t *>(t.blob);
+        }
+        auto ins = items_on_device.emplace(device, t);
+        return ins.first->second.blob ? &ins.first->second.line : nullptr;
     }
 
     int build_search() const {           // call with `mu` held
@@ -849,6 +888,7 @@ int rrx_bitmap_to_bytes(int device, const uint32_t *d_bits, size_t nlines, uint8
     return RRX_OK;
 }
 
+static constexpr size_t kItemsStripesMin = (size_t)1 << 16, kItemsStripesMinBytes = (size_t)8 << 20;
 int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, const uint64_t *d_off, size_t nitems, uint32_t trim,
                       uint8_t *d_accept, void *stream) {
     if (!re || (nitems && (!d_off || !d_accept))) return fail(RRX_ERR_ARG, "null argument");
@@ -857,6 +897,35 @@ int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, cons
     if (rc) return rc;
     HIP_TRY(hipSetDevice(device));
     const uint8_t *b = static_cast<const uint8_t *>(d_bytes);
+    // A large batch on a table engine runs stripe-wise over the byte buffer, the item ends taken from a bitmap built from
+    // the offsets (kernels_table.hip: match_items_stripes_kernel) and the table a copy of the plain one with an END OF ITEM
+    // column.  Needs: trim 0 or 1, at most 126 table states, 16-byte alignment, no item without a byte to carry its mark
+    // (checked on the device; such a batch is redone the other way).  This path waits for the stream (it reads off[0],
+    // off[nitems] and the check's flag).
+    const dev::LineDfaDevice *items = nullptr;
+    if (re->engine == RRX_ENGINE_DFA && trim <= 1 && nitems >= kItemsStripesMin && !(reinterpret_cast<uintptr_t>(d_accept) & 15))
+        items = re->items_table(device);
+    if (items) {
+        hipStream_t st = (hipStream_t)stream;
+        uint64_t first = 0, last = 0;
+        HIP_TRY(hipMemcpyAsync(&first, d_off, sizeof first, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&last, d_off + nitems, sizeof last, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (last > first && last - first >= kItemsStripesMinBytes && !(reinterpret_cast<uintptr_t>(b + first) & 15)) {
+            const size_t nbytes = (size_t)(last - first);
+            std::lock_guard<std::mutex> lock(re->onepass_mu);
+            void *buf = nullptr;
+            rc = re->onepass_for(device, dev::match_items_stripes_scratch(nbytes, nitems, nullptr), &buf);
+            if (rc) return rc;
+            uint32_t *d_flag = nullptr;
+            int le = dev::match_items_stripes_dfa(*items, b + first, nbytes, d_off, nitems, trim, d_accept, buf, &d_flag, stream);
+            if (le) return hip_fail((hipError_t)le, "match_items_stripes launch");
+            uint32_t degenerate = 0;
+            HIP_TRY(hipMemcpyAsync(&degenerate, d_flag, sizeof degenerate, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (!degenerate) return RRX_OK;
+        }
+    }
     int e = re->engine == RRX_ENGINE_NFA_BLOCK ? dev::match_extents_block_nfa(t->block, b, d_off, nitems, trim, d_accept, stream)
             : re->engine == RRX_ENGINE_NFA_WAVE ? dev::match_extents_group_nfa(t->group, b, d_off, nitems, trim, d_accept, stream)
             : re->engine == RRX_ENGINE_NFA ? dev::match_extents_nfa(t->nfa, b, d_off, nitems, trim, d_accept, stream)

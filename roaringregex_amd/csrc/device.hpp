@@ -211,6 +211,12 @@ int search_all(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, const
 // one state -> state map per chunk; maps are then composed in groups until one is left.  `scratch` holds the maps.
 constexpr uint32_t kLongMaxStates = 254;         // row offsets state * 129 stay 16-bit
 constexpr uint32_t kLongGroup = 128;             // maps composed per workgroup and level
+// explicit items (an offsets array over one buffer) stripe-wise: see kernels_table.hip.  The table is the plain one in the
+// wide line-table format with kItemColumns columns: byte values 0..127, 128 = any byte >= 0x80, kItemEndColumn = end of item
+constexpr uint32_t kItemColumns = 131, kItemEndColumn = 129;      // (130 in use, 131 keeps the row stride odd)
+size_t match_items_stripes_scratch(size_t nbytes, size_t nitems, uint32_t *stripe_out);
+int match_items_stripes_dfa(const LineDfaDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *off, size_t nitems, uint32_t trim,
+                            uint8_t *accept, void *scratch, uint32_t **degenerate, void *stream);
 size_t long_scratch_bytes(uint32_t nstates, size_t nbytes, uint32_t *chunk);
 int match_long_dfa(const DfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t chunk, void *scratch, uint8_t *accept,
                    void *stream);

@@ -787,6 +787,213 @@ __global__ __launch_bounds__(256) void search_all_kernel(SearchDevice prog, cons
     if (!FILL) count[i] = k;
 }
 
+// ============================================================================================ explicit items, stripe-wise
+// rrx_match_extents on a large batch (an offsets array over one byte buffer: an Arrow-style string column): the items are
+// lines without a delimiter.  match_extents_kernel gives every lane an item (0.9-1.0 TB/s: consecutive lanes read text an
+// item apart).  Here the buffer is cut into stripes exactly like a corpus, and the item ends come from a bitmap built from
+// the offsets (1 bit per byte) instead of a byte value.  The table is the plain table in the wide line-table format with
+// one more column (abi.cpp: items_table): byte values 0..127 - '\n' an ordinary byte -, 128 = any byte >= 0x80, 129 = END OF
+// ITEM (the verdict of the row, back to the start row):
+//   ENDS = 1 (trim 1: every item is followed by one separator byte): the marked byte is the separator, stepped as byte 129;
+//   ENDS = 2 (trim 0): the marked byte is the item's last byte, a byte 129 is stepped after it.
+// Bytes >= 0x80 of the text are stepped as 0x80.
+template <int ENDS>
+__global__ __launch_bounds__(kThreads) void match_items_stripes_kernel(LineDfaDevice prog, const uint8_t *__restrict__ bytes, size_t nbytes,
+                                                                        uint32_t stripe, const uint64_t *__restrict__ stripe_base,
+                                                                        const uint32_t *__restrict__ ends, uint32_t *__restrict__ accept_bits,
+                                                                        uint32_t stage_off, uint32_t stage_words) {
+    typedef LineDfaEngine<true, false> Engine;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *stage = reinterpret_cast<uint32_t *>(smem + stage_off);
+    Engine eng;
+    eng.load(prog, smem);
+    for (uint32_t i = threadIdx.x; i < stage_words; i += kThreads) stage[i] = 0;
+    __syncthreads();
+    const size_t g0 = (size_t)blockIdx.x * kThreads;
+    const uint64_t window_word = line_of(stripe_base[g0]) >> 5;
+    const size_t g = g0 + threadIdx.x;
+    const size_t start = g * (size_t)stripe;
+    if (start < nbytes) {
+        const size_t stripe_end = start + stripe;
+        const size_t my_end = stripe_end < nbytes ? stripe_end : nbytes;
+        const uint64_t my_base = stripe_base[g];
+        const bool fresh = (my_base & kFreshStripe) != 0;
+        ResultsT<true> res;
+        res.begin_staged(line_of(my_base), window_word, !fresh, accept_bits, stage);
+        res.stage_words = stage_words;
+        typename Engine::State st = fresh ? eng.fresh() : eng.skipping();
+        auto end_bit = [&](size_t pos) -> bool { return (ends[pos >> 5] >> (pos & 31)) & 1u; };
+        // one byte with its end bit: -> (nl, acc) of the step that matters
+        auto step_byte = [&](size_t pos, uint32_t &nl, uint32_t &acc) {
+            uint32_t c = bytes[pos];
+            const bool m = end_bit(pos);
+            if (c >= 0x80u) c = 0x80u;
+            if (ENDS == 1 && m) c = kItemEndColumn;
+            eng.step(st, c, nl, acc);
+            if (ENDS == 2 && m) eng.step(st, kItemEndColumn, nl, acc);
+        };
+        // a text word (no byte >= 0x81 in it) with the end bits m4 of its four bytes
+        auto word = [&](uint32_t w, uint32_t m4) {
+            if constexpr (ENDS == 1) {
+                if (__builtin_amdgcn_ballot_w64(m4 != 0)) {
+                    // bit k of m4 -> byte k (24-bit multiply: v_mul_lo_u32 runs at a quarter of the rate)
+                    const uint32_t t = __umul24(m4, 0x00204081u) & 0x01010101u;
+                    const uint32_t bm = (t << 8) - t;
+                    w = (w & ~bm) | (0x81818181u & bm);
+                }
+                eng.consume_word(st, w, res.bits);
+            } else {
+                uint32_t nl, acc;
+#define RRX_ITEM_BYTE(K)                                                                                                  \
+                eng.template consume<K>(st, w, res.bits);                                                                  \
+                if (__builtin_amdgcn_ballot_w64((m4 >> K) & 1u)) {                                                         \
+                    if ((m4 >> K) & 1u) { eng.step(st, kItemEndColumn, nl, acc); res.bits = (res.bits << nl) | acc; }      \
+                }
+                RRX_ITEM_BYTE(0) RRX_ITEM_BYTE(1) RRX_ITEM_BYTE(2) RRX_ITEM_BYTE(3)
+#undef RRX_ITEM_BYTE
+            }
+        };
+        auto clamp = [](uint32_t w) -> uint32_t { const uint32_t hi = w & 0x80808080u; return w & ~(hi - (hi >> 7)); };      // >= 0x80 -> 0x80
+        size_t pos = start;
+        const uint4 *src = reinterpret_cast<const uint4 *>(bytes + start);
+        const uint4 *esrc = reinterpret_cast<const uint4 *>(ends + (start >> 5));             // 128 bits per 128-byte round
+        constexpr int kSlots = kRound / 16;
+        const int rounds = (int)((my_end - start) / kRound);
+        TextRound<kSlots> buf;
+        uint4 eb = make_uint4(0, 0, 0, 0);
+        if (rounds > 0) { buf.load(src); eb = esrc[0]; }
+        for (int r = 0; r < rounds; r++) {
+            const uint32_t ew[4] = {eb.x, eb.y, eb.z, eb.w};
+            int slot = 0;
+            buf.for_each_slot([&](const uint4 &v) {
+                const uint32_t sb = (ew[slot >> 1] >> (16 * (slot & 1))) & 0xffffu;           // (slot: a constant after inlining)
+                if (__builtin_amdgcn_ballot_w64(((v.x | v.y | v.z | v.w) & 0x80808080u) != 0)) {     // rare on text: one test per 16 bytes
+                    word(clamp(v.x), sb & 15u); word(clamp(v.y), (sb >> 4) & 15u); word(clamp(v.z), (sb >> 8) & 15u); word(clamp(v.w), sb >> 12);
+                } else {
+                    word(v.x, sb & 15u); word(v.y, (sb >> 4) & 15u); word(v.z, (sb >> 8) & 15u); word(v.w, sb >> 12);
+                }
+                if (res.bits >> 15) res.flush();
+                slot++;
+            });
+            if ((r & 3) == 3) res.flush();
+            if (r + 1 < rounds) { buf.load(src + (size_t)(r + 1) * kSlots); eb = esrc[r + 1]; }
+        }
+        pos += (size_t)rounds * kRound;
+        for (; pos < my_end; pos++) {                                 // tail of the buffer inside my stripe
+            uint32_t nl, acc;
+            step_byte(pos, nl, acc);
+            res.push(nl, acc);
+            if (res.bits >> 30) res.flush();
+        }
+        res.flush();
+        // the item that straddles my stripe end is mine if it started here: follow it to its end
+        const bool started = fresh || res.seen > 0;
+        if (started && !end_bit(my_end - 1)) {
+            uint32_t nl = 0, acc = 0;
+            // 16 bytes and their 16 end bits per turn (pos is 16-byte aligned: stripes are multiples of 128; one byte and one
+            // bitmap word per turn was a chain of 150 memory round trips for the slowest lane of a wave on 95-byte items)
+            while (pos + 16 <= nbytes && !nl) {
+                const uint4 v = *reinterpret_cast<const uint4 *>(bytes + pos);
+                const uint32_t e16 = (ends[pos >> 5] >> (pos & 31)) & 0xffffu;
+                const uint32_t w[4] = {clamp(v.x), clamp(v.y), clamp(v.z), clamp(v.w)};
+#pragma unroll
+                for (int k = 0; k < 16; k++) {
+                    if (!nl) {
+                        uint32_t c = (w[k >> 2] >> (8 * (k & 3))) & 0xffu;
+                        const bool m = (e16 >> k) & 1u;
+                        if (ENDS == 1 && m) c = kItemEndColumn;
+                        eng.step(st, c, nl, acc);
+                        if (ENDS == 2 && m) eng.step(st, kItemEndColumn, nl, acc);
+                    }
+                }
+                pos += 16;
+            }
+            for (; pos < nbytes && !nl; pos++) step_byte(pos, nl, acc);
+            if (!nl) eng.step(st, kItemEndColumn, nl, acc);            // (cannot happen: the last item ends where the buffer ends)
+            res.push(nl, acc);
+        }
+        res.finish();
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < stage_words; i += kThreads) {
+        const uint32_t v = stage[i];
+        if (v) atomicOr(&accept_bits[window_word + i], v);
+    }
+}
+// Bitmap of item ends from the offsets (positions relative to off[0]); *flag |= 1 if an item has no byte to carry its mark.
+// The ends are sorted: the 256 items of a workgroup mark a contiguous range of bitmap words, [word of its first mark, word
+// of the next workgroup's first mark].  The range is assembled in LDS, tile by tile, and written out whole - zero words
+// included, consecutive lanes consecutive words - with atomics only for its first and last word, which the neighbouring
+// workgroups share.  (One atomic per item: 0.12 ms for 22 M items of 95 bytes, 1.0 ms for 55 M of 19; one 4-byte store per
+// marked word: 0.34 / 0.83 ms - scattered partial writes into 128 MB.)
+constexpr uint32_t kEndsTile = 4096, kEndsPerLane = 4, kEndsItems = 256 * kEndsPerLane;      // items per workgroup
+__global__ __launch_bounds__(256) void item_ends_kernel(const uint64_t *__restrict__ off, size_t nitems, uint32_t trim, uint32_t *__restrict__ ends,
+                                                        uint32_t *__restrict__ flag) {
+    __shared__ uint32_t tile[kEndsTile];
+    const size_t i0 = (size_t)blockIdx.x * kEndsItems;
+    const size_t i1 = i0 + kEndsItems < nitems ? i0 + kEndsItems : nitems;     // first item of the next workgroup (nitems: none)
+    const uint64_t base = off[0];
+    auto mark_of = [&](size_t k) -> uint64_t {                      // position of item k's mark (a degenerate item: of its start)
+        const uint64_t e = off[k + 1];
+        return (e > base ? e - 1 : base) - base;
+    };
+    uint64_t word[kEndsPerLane];
+    uint32_t mask[kEndsPerLane];
+    uint64_t ob[kEndsPerLane], oe[kEndsPerLane];
+#pragma unroll
+    for (uint32_t k = 0; k < kEndsPerLane; k++) {                   // (all loads first: four round trips in flight)
+        const size_t i = i0 + (size_t)k * 256 + threadIdx.x;
+        ob[k] = i < nitems ? off[i] : 0;
+        oe[k] = i < nitems ? off[i + 1] : 0;
+    }
+    bool degenerate = false;
+#pragma unroll
+    for (uint32_t k = 0; k < kEndsPerLane; k++) {
+        const size_t i = i0 + (size_t)k * 256 + threadIdx.x;
+        word[k] = ~0ull; mask[k] = 0;
+        if (i < nitems) {
+            if (oe[k] <= ob[k] || oe[k] - ob[k] < trim) degenerate = true;     // trim 1: at least the separator; trim 0: at least one byte
+            else { const uint64_t pos = oe[k] - 1 - base; word[k] = pos >> 5; mask[k] = 1u << (pos & 31); }
+        }
+    }
+    if (degenerate) atomicOr(flag, 1u);
+    const uint64_t F = mark_of(i0) >> 5;
+    const uint64_t L = i1 < nitems ? mark_of(i1) >> 5 : mark_of(nitems - 1) >> 5;
+    for (uint64_t T = F; T <= L; T += kEndsTile) {
+        const uint64_t n = L - T + 1 < kEndsTile ? L - T + 1 : kEndsTile;     // words of this tile
+        for (uint32_t j = threadIdx.x; j < n; j += 256) tile[j] = 0;
+        __syncthreads();
+#pragma unroll
+        for (uint32_t k = 0; k < kEndsPerLane; k++)
+            if (word[k] >= T && word[k] < T + kEndsTile) atomicOr(&tile[(uint32_t)(word[k] - T)], mask[k]);
+        __syncthreads();
+        for (uint32_t j = threadIdx.x; j < n; j += 256) {
+            const uint64_t w = T + j;
+            const uint32_t v = tile[j];
+            if (w == F || w == L) { if (v) atomicOr(&ends[w], v); }
+            else ends[w] = v;
+        }
+        __syncthreads();
+    }
+}
+// stripe_base[g] = items that end before stripe g | kFreshStripe if the byte in front of it is marked; entry nstripes = all.
+// The item ends are sorted: a binary search per stripe over the offsets (no count pass over the bitmap, no scan).
+__global__ __launch_bounds__(256) void item_stripe_base_kernel(const uint64_t *__restrict__ off, size_t nitems, uint32_t stripe, size_t nstripes,
+                                                               uint64_t *__restrict__ stripe_base) {
+    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (g > nstripes) return;
+    if (g == nstripes) { stripe_base[g] = nitems; return; }
+    // marks are at off[i + 1] - 1 - off[0]; the number of marks < start = the number of i with off[i + 1] - off[0] <= start
+    const uint64_t base = off[0], target = base + g * (uint64_t)stripe;
+    size_t lo = 0, hi = nitems;                                      // first i with off[i + 1] > target
+    while (lo < hi) {
+        const size_t mid = lo + (hi - lo) / 2;
+        if (off[mid + 1] <= target) lo = mid + 1; else hi = mid;
+    }
+    const bool fresh = g == 0 || (lo > 0 && off[lo] == target);      // the item before ends exactly at my first byte
+    stripe_base[g] = (uint64_t)lo | (fresh ? kFreshStripe : 0);
+}
+
 // ============================================================================================ one long string
 // Chunk maps.  LDS: the plain DFA widened to one u16 entry per (state, byte value 0..127 | >= 0x80), entry = row
 // offset of the next state (state * 129), so a step is one clamp, one add and one ds_read_u16.
@@ -1090,6 +1297,60 @@ int match_long_dfa(const DfaDevice &p, const uint8_t *bytes, size_t nbytes, uint
     }
     hipLaunchKernelGGL(long_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cur, p, accept);
     return (int)hipGetLastError();
+}
+// Scratch of match_items_stripes: [ends bitmap | flag u32 | counts u32 (nstripes + 1) | base u64 (nstripes + 1 + scan) | result bitmap]
+static size_t items_align(size_t x) { return (x + 255) & ~(size_t)255; }
+size_t match_items_stripes_scratch(size_t nbytes, size_t nitems, uint32_t *stripe_out) {
+    const uint32_t stripe = pick_stripe(nbytes);
+    const size_t nstripes = (nbytes + stripe - 1) / stripe;
+    if (stripe_out) *stripe_out = stripe;
+    return items_align(((nbytes + 31) / 32 + 4) * 4) + 256 + items_align((nstripes + 1) * 4) + items_align((nstripes + 1 + scan_scratch_words(nstripes)) * 8) +
+           items_align(((nitems + 31) / 32 + 4) * 4);
+}
+// trim 0 or 1; `bytes` is the buffer from off[0] on (16-byte aligned), nbytes = off[nitems] - off[0].  *degenerate (device
+// u32 in the scratch, read by the caller after the stream is done) != 0: an item without a byte for its mark - the result
+// is not valid, use the lane-per-item kernel.
+int match_items_stripes_dfa(const LineDfaDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *off, size_t nitems, uint32_t trim,
+                            uint8_t *accept, void *scratch, uint32_t **degenerate, void *stream) {
+    if (!p.wide || p.in_global || p.stride != (kItemColumns << p.rep_log2) || trim > 1 || !nitems || !nbytes) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t stripe = 0;
+    (void)match_items_stripes_scratch(nbytes, nitems, &stripe);
+    const size_t nstripes = (nbytes + stripe - 1) / stripe;
+    uint8_t *sp = static_cast<uint8_t *>(scratch);
+    uint32_t *ends = reinterpret_cast<uint32_t *>(sp);                sp += items_align(((nbytes + 31) / 32 + 4) * 4);
+    uint32_t *flag = reinterpret_cast<uint32_t *>(sp);                sp += 256;
+    uint32_t *counts = reinterpret_cast<uint32_t *>(sp);              sp += items_align((nstripes + 1) * 4);
+    uint64_t *base = reinterpret_cast<uint64_t *>(sp);                sp += items_align((nstripes + 1 + scan_scratch_words(nstripes)) * 8);
+    uint32_t *bits = reinterpret_cast<uint32_t *>(sp);
+    *degenerate = flag;
+    hipError_t e = hipMemsetAsync(ends, 0, items_align(((nbytes + 31) / 32 + 4) * 4) + 256, st);       // bitmap and flag
+    if (e == hipSuccess) e = hipMemsetAsync(bits, 0, ((nitems + 31) / 32 + 4) * 4, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(item_ends_kernel, dim3((unsigned)((nitems + kEndsItems - 1) / kEndsItems)), dim3(256), 0, st, off, nitems, trim, ends, flag);
+    hipLaunchKernelGGL(item_stripe_base_kernel, dim3((unsigned)((nstripes + 1 + 255) / 256)), dim3(256), 0, st, off, nitems, stripe, nstripes, base);
+    (void)counts;
+    int rc = 0;
+    const size_t table_bytes = LineDfaEngine<true, false>::lds_bytes(p);
+    const uint32_t stage_off = (uint32_t)((table_bytes + 15) & ~(size_t)15);
+    const size_t half_cu = 80 * 1024;
+    const uint32_t stage_words = stage_off + kStageWords * sizeof(uint32_t) >= half_cu ? kStageWords : (uint32_t)((half_cu - stage_off) / 4);
+    const size_t lds = stage_off + (size_t)stage_words * sizeof(uint32_t);
+    const size_t blocks = (nstripes + kThreads - 1) / kThreads;
+    if (trim == 1) {
+        static LdsAttr attr;
+        e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(match_items_stripes_kernel<1>), lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(match_items_stripes_kernel<1>, dim3((unsigned)blocks), dim3(kThreads), lds, st, p, bytes, nbytes, stripe, base, ends, bits, stage_off, stage_words);
+    } else {
+        static LdsAttr attr;
+        e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(match_items_stripes_kernel<2>), lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(match_items_stripes_kernel<2>, dim3((unsigned)blocks), dim3(kThreads), lds, st, p, bytes, nbytes, stripe, base, ends, bits, stage_off, stage_words);
+    }
+    rc = (int)hipGetLastError();
+    if (rc) return rc;
+    return expand_bits(bits, nitems, accept, stream);
 }
 int match_extents_dfa(const DfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim, uint8_t *accept,
                       void *stream) {

@@ -567,6 +567,72 @@ def test_extents_with_unaligned_items_of_many_lengths():
         assert list(got) == want, r.engine_name
 
 
+def test_explicit_items_stripe_wise():
+    """rrx_match_extents on large batches (an offsets array over one buffer) takes the stripe-wise kernel: item ends from a
+    bitmap built from the offsets, the plain table with an end-of-item column.  Checked against the lane-per-item kernel
+    (the same call on pieces of 50000 items, below the threshold) and, where the items are the lines of a corpus, against
+    the batch kernel: trim 1 with '\n' and with ';' as the separator, trim 0 (no separator at all), items that hold a real
+    '\n', 0x00 and bytes >= 0x80, empty items (trim 0: the batch falls back), a pattern that survives a '\n'."""
+    import synth
+    n = 24 << 20
+
+    def pieces(r, dev, off, trim):
+        out = []
+        for lo in range(0, off.numel() - 1, 50000):
+            out.append(r.match_extents(dev, off[lo:lo + 50001].contiguous(), trim=trim))
+        return torch.cat(out)
+
+    for kind, pattern in (("url", U2), ("email", EMAIL)):
+        host = synth.corpus(kind, 9, n).copy()
+        rng = np.random.default_rng(5)
+        spots = rng.integers(0, n, 200)
+        host[spots[:100]] = 0
+        host[spots[100:]] = 0xC3
+        host[host == 10][:0]                                            # (separators stay where they are)
+        dev = torch.from_numpy(host).cuda()
+        nl = torch.nonzero(dev == 10).flatten()
+        off = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), nl + 1]).contiguous()
+        for engine in (rr.ENGINE_AUTO, rr.ENGINE_DFA):
+            r = rr.RRegex(pattern, engine)
+            want = r.match_corpus(rr.Corpus(dev))[:off.numel() - 1].bool()
+            # trim 1, separator '\n'
+            got = r.match_extents(dev, off, trim=1).bool()
+            assert torch.equal(got, want), (kind, r.engine_name, "trim 1")
+            # trim 1, separator ';' and real '\n' bytes inside some items (they reject their items)
+            h2 = host.copy(); h2[h2 == 10] = ord(";")
+            inside = np.nonzero(h2 != ord(";"))[0][::100003]
+            h2[inside] = 10
+            d2 = torch.from_numpy(h2).cuda()
+            got = r.match_extents(d2, off, trim=1).bool()
+            ref = pieces(r, d2, off, 1).bool()
+            assert torch.equal(got, ref), (kind, r.engine_name, "trim 1, ';'")
+            assert int((got != want).sum()) <= len(inside)
+            # trim 0: the same items without any separator
+            keep = host != 10
+            h0 = host[keep]
+            lens = np.diff(np.concatenate([[0], np.nonzero(host == 10)[0] + 1])) - 1
+            off0 = torch.from_numpy(np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)).cuda()
+            d0 = torch.from_numpy(h0.copy()).cuda()
+            got = r.match_extents(d0, off0, trim=0).bool()
+            if int((torch.from_numpy(lens) == 0).sum()):                 # empty items: the batch went the other way; same answer
+                pass
+            assert torch.equal(got, want), (kind, r.engine_name, "trim 0")
+            # trim 0 without empty items (so that the stripe-wise kernel is the one that runs)
+            nz = np.nonzero(lens > 0)[0]
+            if len(nz) != len(lens):
+                lens1 = lens[nz]
+                off1 = torch.from_numpy(np.concatenate([[0], np.cumsum(lens1)]).astype(np.int64)).cuda()
+                got = r.match_extents(d0, off1, trim=0).bool()
+                assert torch.equal(got, want[torch.from_numpy(nz).cuda()]), (kind, r.engine_name, "trim 0, no empty items")
+    # a pattern for which '\n' is an ordinary, matchable byte: same answers as on pieces
+    host = synth.corpus("email", 4, n)
+    dev = torch.from_numpy(host).cuda()
+    nl = torch.nonzero(dev == 10).flatten()
+    off = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), nl + 1]).contiguous()
+    r = rr.RRegex("[^@]*")
+    assert torch.equal(r.match_extents(dev, off, trim=0), pieces(r, dev, off, 0))
+
+
 # ------------------------------------------------------------------------------------------ one long string
 def test_one_long_string_is_stepped_in_parallel_chunks():
     """regex.h:156-159 consumes ONE string; rrx_match_string cuts a long one into chunks, steps every chunk from every

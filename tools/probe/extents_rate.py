@@ -28,3 +28,20 @@ for w in ("url", "email"):
         torch.cuda.synchronize()
         t = (time.perf_counter() - t0) / 3
         print("%-6s %-20s items %9d  extents %8.1f GB/s  (%.2f ms)" % (w, r.engine_name, off.numel() - 1, n / t / 1e9, t * 1e3), flush=True)
+    # the same items without any separator (trim 0: an Arrow-style column), empty items dropped
+    keep = host != 10
+    lens = np.diff(np.concatenate([[0], np.nonzero(host == 10)[0] + 1])) - 1
+    nz = lens > 0
+    off0 = torch.from_numpy(np.concatenate([[0], np.cumsum(lens[nz])]).astype(np.int64)).cuda()
+    d0 = torch.from_numpy(host[keep].copy()).cuda()
+    r = rr.RRegex(pat)
+    want0 = r.match_corpus(corpus)[:off.numel() - 1][torch.from_numpy(nz).cuda()]
+    got = r.match_extents(d0, off0, trim=0)
+    assert torch.equal(got.bool(), want0.bool()), (w, "trim 0")
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        r.match_extents(d0, off0, trim=0)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / 3
+    print("%-6s %-20s items %9d  extents %8.1f GB/s  (%.2f ms)  trim 0" % (w, r.engine_name, off0.numel() - 1, d0.numel() / t / 1e9, t * 1e3), flush=True)
