@@ -598,6 +598,13 @@ def test_explicit_items_stripe_wise():
             # trim 1, separator '\n'
             got = r.match_extents(dev, off, trim=1).bool()
             assert torch.equal(got, want), (kind, r.engine_name, "trim 1")
+            # a batch that starts in the middle of the buffer: at a 16-byte boundary (stripe-wise) and not (lane per item)
+            o = off.cpu().numpy()
+            k_al = int(np.nonzero((o[1000:2000] % 16) == 0)[0][0]) + 1000
+            k_un = int(np.nonzero((o[1000:2000] % 16) != 0)[0][0]) + 1000
+            for k in (k_al, k_un):
+                got = r.match_extents(dev, off[k:].contiguous(), trim=1).bool()
+                assert torch.equal(got, want[k:]), (kind, r.engine_name, "from item", k)
             # trim 1, separator ';' and real '\n' bytes inside some items (they reject their items)
             h2 = host.copy(); h2[h2 == 10] = ord(";")
             inside = np.nonzero(h2 != ord(";"))[0][::100003]
