@@ -631,6 +631,20 @@ def test_explicit_items_stripe_wise():
                 off1 = torch.from_numpy(np.concatenate([[0], np.cumsum(lens1)]).astype(np.int64)).cuda()
                 got = r.match_extents(d0, off1, trim=0).bool()
                 assert torch.equal(got, want[torch.from_numpy(nz).cuda()]), (kind, r.engine_name, "trim 0, no empty items")
+    # items from 1 byte to 200 KB (longer than many stripes: lanes whose stripe holds no item end at all), separators of any
+    # value - also bytes the pattern matches -, a buffer whose last stripe is partial
+    rng = np.random.default_rng(23)
+    lens = rng.choice([1, 2, 5, 30, 300, 5000, 200_000], size=70_000, p=[0.2, 0.2, 0.25, 0.25, 0.09, 0.009, 0.001])
+    r = rr.RRegex("(a|b)*abb")
+    for trim in (0, 1):
+        tot = int(lens.sum()) + trim * len(lens)
+        text = np.frombuffer(b"ab", dtype=np.uint8)[rng.integers(0, 2, size=tot)].copy()
+        ends = np.cumsum(lens + trim)
+        if trim:
+            text[ends - 1] = np.frombuffer(b"ab\nx", dtype=np.uint8)[rng.integers(0, 4, size=len(lens))]
+        offs = torch.from_numpy(np.concatenate([[0], ends]).astype(np.int64)).cuda()
+        dev = torch.from_numpy(text).cuda()
+        assert torch.equal(r.match_extents(dev, offs, trim=trim), pieces(r, dev, offs, trim)), ("long items", trim)
     # a pattern for which '\n' is an ordinary, matchable byte: same answers as on pieces
     host = synth.corpus("email", 4, n)
     dev = torch.from_numpy(host).cuda()
