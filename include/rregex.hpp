@@ -142,6 +142,11 @@ public:
         auto *f = static_cast<DeviceIterFactory *>(iter_factory.get());
         if (rrx_search_corpus(f->handle(), corpus, d_start, d_end, stream) != RRX_OK) throw std::runtime_error(rrx_last_error());
     }
+    // a batch of explicit items (an offsets array over one buffer) indexed once with rrx_items_create: one byte per item
+    void match_items(const rrx_items *items, uint8_t *d_accept, void *stream = nullptr) {
+        auto *f = static_cast<DeviceIterFactory *>(iter_factory.get());
+        if (rrx_match_items(f->handle(), items, d_accept, stream) != RRX_OK) throw std::runtime_error(rrx_last_error());
+    }
     // every lazy match of every string, left to right, in one call (rrx_search_all): d_first[i] (nlines + 1 entries) = slot
     // of string i's first match; returns the number of matches - if it exceeds `cap` (the entries d_start / d_end hold),
     // those beyond were not written: call again with arrays of that size.  Synchronous.

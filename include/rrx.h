@@ -117,6 +117,19 @@ int rrx_search_all(const rrx_regex *re, const rrx_corpus *corpus, uint64_t *d_fi
 int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, const uint64_t *d_off, size_t nitems,
                       uint32_t trim, uint8_t *d_accept, void *stream);
 
+/* A batch of items indexed ONCE and matched by many patterns (what rrx_corpus is for delimited text): the item-end
+ * bitmap and the stripe index of section DESIGN.md 6.5 are built here (synchronous) and kept.  rrx_match_items fills
+ * d_accept[i] (one byte per item, 16-byte aligned for the fast path) on `stream`; batches or patterns that do not admit the
+ * stripe-wise kernel run as rrx_match_extents.  d_bytes and d_off must outlive the handle.  One match at a time per
+ * handle (it owns the result scratch).                                                                              */
+typedef struct rrx_items rrx_items;
+int rrx_items_create(int device, const void *d_bytes, const uint64_t *d_off, size_t nitems, uint32_t trim, void *stream,
+                     rrx_items **out);
+size_t rrx_items_count(const rrx_items *items);
+int rrx_items_stripe_wise(const rrx_items *items);         /* 1: the batch admits the stripe-wise kernel */
+void rrx_items_free(rrx_items *items);
+int rrx_match_items(const rrx_regex *re, const rrx_items *items, uint8_t *d_accept, void *stream);
+
 /* ONE device-resident string of any length (regex.h:156-159: operator++ consumes the whole string; '\n' and every
  * other byte are ordinary, a NUL or a byte >= 0x80 rejects).  d_accept[0] = 1 iff accepted.  Strings of 32 KiB and
  * more are split into chunks that are stepped in parallel from every table state (automata with <= 254 table

@@ -26,7 +26,8 @@ ABI_SYMBOLS = (
     "rrx_program_words",
     "rrx_corpus_create", "rrx_corpus_create_ex", "rrx_corpus_stripe_bytes", "rrx_corpus_num_lines", "rrx_corpus_num_bytes", "rrx_corpus_free", "rrx_corpus_bitmap_words",
     "rrx_match_corpus", "rrx_match_device", "rrx_search_corpus", "rrx_search_all_count", "rrx_search_all_fill", "rrx_search_all", "rrx_bitmap_to_bytes",
-    "rrx_match_extents", "rrx_match_string", "rrx_match_host", "rrx_match_cstr",
+    "rrx_match_extents", "rrx_items_create", "rrx_items_count", "rrx_items_stripe_wise", "rrx_items_free", "rrx_match_items",
+    "rrx_match_string", "rrx_match_host", "rrx_match_cstr",
 )
 
 
@@ -76,6 +77,11 @@ def _load():
         "rrx_match_device": (i32, [vp, i32, vp, sz, vp, sz, C.POINTER(sz), vp]),
         "rrx_bitmap_to_bytes": (i32, [i32, vp, sz, vp, vp]),
         "rrx_match_extents": (i32, [vp, i32, vp, vp, sz, u32, vp, vp]),
+        "rrx_items_create": (i32, [i32, vp, vp, sz, u32, vp, C.POINTER(vp)]),
+        "rrx_items_count": (sz, [vp]),
+        "rrx_items_stripe_wise": (i32, [vp]),
+        "rrx_items_free": (None, [vp]),
+        "rrx_match_items": (i32, [vp, vp, vp, vp]),
         "rrx_match_string": (i32, [vp, i32, vp, sz, vp, vp]),
         "rrx_search_corpus": (i32, [vp, vp, vp, vp, vp]),
         "rrx_search_all_count": (i32, [vp, vp, vp, vp]),
@@ -201,6 +207,36 @@ class Corpus:
         return _L.rrx_corpus_stripe_bytes(self._h)
 
 
+class Items:
+    """A device-resident batch of explicit items - one byte buffer and an offsets array, item i = data[offsets[i] :
+    offsets[i + 1] - trim] - indexed once (rrx_items) and matched by many patterns: RRegex.match_items."""
+
+    def __init__(self, data, offsets, trim=0, stream=None):
+        import torch
+        assert data.is_cuda and data.dtype == torch.uint8 and data.is_contiguous()
+        assert offsets.is_cuda and offsets.dtype in (torch.int64, torch.uint64) and offsets.is_contiguous() and offsets.numel() >= 1
+        self.data, self.offsets, self.trim = data, offsets, trim       # kept alive: the handle points into them
+        self.device = data.device.index
+        self._h = C.c_void_p()
+        with _on(self.device, stream):
+            _check(_L.rrx_items_create(self.device, C.c_void_p(data.data_ptr() if data.numel() else 0), C.c_void_p(offsets.data_ptr()),
+                                       offsets.numel() - 1, trim, _stream_ptr(stream), C.byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None) and _L is not None:
+            _L.rrx_items_free(self._h)
+            self._h = None
+
+    @property
+    def num_items(self):
+        return _L.rrx_items_count(self._h)
+
+    @property
+    def stripe_wise(self):
+        """True if the batch admits the stripe-wise kernel (else every match runs lane per item)."""
+        return bool(_L.rrx_items_stripe_wise(self._h))
+
+
 class RRegex:
     """regex.h:212-228.  RRegex(pattern) compiles on the host (Parser.cpp:161-170)."""
 
@@ -319,6 +355,17 @@ class RRegex:
                     break
                 cap = total.value
         return first, start[:total.value], end[:total.value]
+
+    def match_items(self, items, out=None, stream=None):
+        """One byte per item of an indexed batch (Items)."""
+        import torch
+        n = items.num_items
+        with _on(items.device, stream):
+            if out is None:
+                out = torch.empty(n, dtype=torch.uint8, device=items.data.device)
+            assert out.is_cuda and out.dtype == torch.uint8 and out.numel() >= n
+            _check(_L.rrx_match_items(self._h, items._h, C.c_void_p(out.data_ptr() if n else 0), _stream_ptr(stream)))
+        return out[:n]
 
     def match_extents(self, data, offsets, trim=0, out=None, stream=None):
         """item i = data[offsets[i] : offsets[i+1] - trim]; '\\n' is an ordinary character."""

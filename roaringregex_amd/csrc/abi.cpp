@@ -915,10 +915,12 @@ int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, cons
             const size_t nbytes = (size_t)(last - first);
             std::lock_guard<std::mutex> lock(re->onepass_mu);
             void *buf = nullptr;
-            rc = re->onepass_for(device, dev::match_items_stripes_scratch(nbytes, nitems, nullptr), &buf);
+            const size_t ib = dev::items_index_bytes(nbytes);
+            rc = re->onepass_for(device, ib + dev::items_result_bytes(nitems), &buf);
             if (rc) return rc;
             uint32_t *d_flag = nullptr;
-            int le = dev::match_items_stripes_dfa(*items, b + first, nbytes, d_off, nitems, trim, d_accept, buf, &d_flag, stream);
+            int le = dev::items_index_build(nbytes, d_off, nitems, trim, buf, &d_flag, stream);
+            if (!le) le = dev::items_match(*items, b + first, nbytes, nitems, trim, buf, static_cast<uint8_t *>(buf) + ib, d_accept, stream);
             if (le) return hip_fail((hipError_t)le, "match_items_stripes launch");
             uint32_t degenerate = 0;
             HIP_TRY(hipMemcpyAsync(&degenerate, d_flag, sizeof degenerate, hipMemcpyDeviceToHost, st));
@@ -932,6 +934,78 @@ int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, cons
                                          : dev::match_extents_dfa(t->dfa, b, d_off, nitems, trim, d_accept, stream);
     if (e) return hip_fail((hipError_t)e, "match_extents launch");
     return RRX_OK;
+}
+
+// A batch of items indexed once (item-end bitmap + stripe base), matched by many patterns: rrx_corpus' counterpart for an
+// offsets array.  stripes = false: the batch does not admit the stripe-wise kernel (trim > 1, an empty item at trim 0,
+// alignment); rrx_match_items then runs the lane-per-item kernel.
+struct rrx_items {
+    int device = 0;
+    const uint8_t *d_bytes = nullptr;
+    const uint64_t *d_off = nullptr;
+    size_t nitems = 0, nbytes = 0;       // nbytes = off[nitems] - off[0]
+    uint64_t first = 0;
+    uint32_t trim = 0;
+    bool stripes = false;
+    void *d_index = nullptr;
+    mutable std::mutex mu;
+    mutable void *d_result = nullptr;    // result bitmap of a match (one match at a time per handle)
+};
+int rrx_items_create(int device, const void *d_bytes, const uint64_t *d_off, size_t nitems, uint32_t trim, void *stream, rrx_items **out) {
+    if (!out || (nitems && (!d_bytes || !d_off))) return fail(RRX_ERR_ARG, "null argument");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(device));
+    rrx_items *it = new rrx_items();
+    it->device = device; it->d_bytes = static_cast<const uint8_t *>(d_bytes); it->d_off = d_off; it->nitems = nitems; it->trim = trim;
+    hipStream_t st = (hipStream_t)stream;
+    if (nitems && trim <= 1) {
+        uint64_t first = 0, last = 0;
+        hipError_t e = hipMemcpyAsync(&first, d_off, sizeof first, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(&last, d_off + nitems, sizeof last, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { delete it; return hip_fail(e, "items offsets readback"); }
+        it->first = first;
+        if (last > first && !(reinterpret_cast<uintptr_t>(it->d_bytes + first) & 15)) {
+            it->nbytes = (size_t)(last - first);
+            e = hipMalloc(&it->d_index, dev::items_index_bytes(it->nbytes));
+            if (e == hipSuccess) e = hipMalloc(&it->d_result, dev::items_result_bytes(nitems));
+            if (e != hipSuccess) { rrx_items_free(it); return hip_fail(e, "hipMalloc(items index)"); }
+            uint32_t *d_flag = nullptr;
+            int le = dev::items_index_build(it->nbytes, d_off, nitems, trim, it->d_index, &d_flag, stream);
+            uint32_t degenerate = 1;
+            if (!le) { e = hipMemcpyAsync(&degenerate, d_flag, sizeof degenerate, hipMemcpyDeviceToHost, st); if (e == hipSuccess) e = hipStreamSynchronize(st); }
+            if (le || e != hipSuccess) { rrx_items_free(it); return le ? hip_fail((hipError_t)le, "items index launch") : hip_fail(e, "items index"); }
+            it->stripes = degenerate == 0;
+        }
+    }
+    *out = it;
+    return RRX_OK;
+}
+size_t rrx_items_count(const rrx_items *it) { return it ? it->nitems : 0; }
+int rrx_items_stripe_wise(const rrx_items *it) { return it && it->stripes ? 1 : 0; }
+void rrx_items_free(rrx_items *it) {
+    if (!it) return;
+    (void)hipSetDevice(it->device);
+    if (it->d_index) (void)hipFree(it->d_index);
+    if (it->d_result) (void)hipFree(it->d_result);
+    delete it;
+}
+int rrx_match_items(const rrx_regex *re, const rrx_items *it, uint8_t *d_accept, void *stream) {
+    if (!re || !it || (it->nitems && !d_accept)) return fail(RRX_ERR_ARG, "null argument");
+    if (!it->nitems) return RRX_OK;
+    if (it->stripes && re->engine == RRX_ENGINE_DFA && !(reinterpret_cast<uintptr_t>(d_accept) & 15)) {
+        const DeviceTables *t;
+        int rc = re->tables(it->device, &t);
+        if (rc) return rc;
+        if (const dev::LineDfaDevice *items = re->items_table(it->device)) {
+            HIP_TRY(hipSetDevice(it->device));
+            std::lock_guard<std::mutex> lock(it->mu);
+            int le = dev::items_match(*items, it->d_bytes + it->first, it->nbytes, it->nitems, it->trim, it->d_index, it->d_result, d_accept, stream);
+            if (le) return hip_fail((hipError_t)le, "match_items launch");
+            return RRX_OK;
+        }
+    }
+    return rrx_match_extents(re, it->device, it->d_bytes, it->d_off, it->nitems, it->trim, d_accept, stream);
 }
 
 // One device-resident string of any length.  Long strings take the chunk-map path when the automaton has a small

@@ -214,9 +214,11 @@ constexpr uint32_t kLongGroup = 128;             // maps composed per workgroup 
 // explicit items (an offsets array over one buffer) stripe-wise: see kernels_table.hip.  The table is the plain one in the
 // wide line-table format with kItemColumns columns: byte values 0..127, 128 = any byte >= 0x80, kItemEndColumn = end of item
 constexpr uint32_t kItemColumns = 131, kItemEndColumn = 129;      // (130 in use, 131 keeps the row stride odd)
-size_t match_items_stripes_scratch(size_t nbytes, size_t nitems, uint32_t *stripe_out);
-int match_items_stripes_dfa(const LineDfaDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *off, size_t nitems, uint32_t trim,
-                            uint8_t *accept, void *scratch, uint32_t **degenerate, void *stream);
+size_t items_index_bytes(size_t nbytes);                 // item-end bitmap, flag, stripe base
+size_t items_result_bytes(size_t nitems);                // result bitmap of one match
+int items_index_build(size_t nbytes, const uint64_t *off, size_t nitems, uint32_t trim, void *index, uint32_t **flag, void *stream);
+int items_match(const LineDfaDevice &p, const uint8_t *bytes, size_t nbytes, size_t nitems, uint32_t trim, const void *index, void *result,
+                uint8_t *accept, void *stream);
 size_t long_scratch_bytes(uint32_t nstates, size_t nbytes, uint32_t *chunk);
 int match_long_dfa(const DfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t chunk, void *scratch, uint8_t *accept,
                    void *stream);

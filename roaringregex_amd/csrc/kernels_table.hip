@@ -1298,39 +1298,46 @@ int match_long_dfa(const DfaDevice &p, const uint8_t *bytes, size_t nbytes, uint
     hipLaunchKernelGGL(long_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, cur, p, accept);
     return (int)hipGetLastError();
 }
-// Scratch of match_items_stripes: [ends bitmap | flag u32 | counts u32 (nstripes + 1) | base u64 (nstripes + 1 + scan) | result bitmap]
+// The index of a batch of items (kept by an rrx_items handle, or built in scratch by rrx_match_extents):
+//   [ends bitmap, 1 bit per byte | flag u32 (an item without a byte for its mark) | stripe base u64 (nstripes + 1)]
+// and, per match, a result bitmap of nitems bits.
 static size_t items_align(size_t x) { return (x + 255) & ~(size_t)255; }
-size_t match_items_stripes_scratch(size_t nbytes, size_t nitems, uint32_t *stripe_out) {
-    const uint32_t stripe = pick_stripe(nbytes);
-    const size_t nstripes = (nbytes + stripe - 1) / stripe;
-    if (stripe_out) *stripe_out = stripe;
-    return items_align(((nbytes + 31) / 32 + 4) * 4) + 256 + items_align((nstripes + 1) * 4) + items_align((nstripes + 1 + scan_scratch_words(nstripes)) * 8) +
-           items_align(((nitems + 31) / 32 + 4) * 4);
+static size_t items_ends_bytes(size_t nbytes) { return items_align(((nbytes + 31) / 32 + 4) * 4); }
+uint32_t items_stripe(size_t nbytes) { return pick_stripe(nbytes); }
+size_t items_index_bytes(size_t nbytes) {
+    const size_t nstripes = (nbytes + items_stripe(nbytes) - 1) / items_stripe(nbytes);
+    return items_ends_bytes(nbytes) + 256 + items_align((nstripes + 1) * 8);
 }
-// trim 0 or 1; `bytes` is the buffer from off[0] on (16-byte aligned), nbytes = off[nitems] - off[0].  *degenerate (device
-// u32 in the scratch, read by the caller after the stream is done) != 0: an item without a byte for its mark - the result
-// is not valid, use the lane-per-item kernel.
-int match_items_stripes_dfa(const LineDfaDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *off, size_t nitems, uint32_t trim,
-                            uint8_t *accept, void *scratch, uint32_t **degenerate, void *stream) {
+size_t items_result_bytes(size_t nitems) { return items_align(((nitems + 31) / 32 + 4) * 4); }
+// trim 0 or 1; the buffer starts at off[0] and holds nbytes = off[nitems] - off[0] bytes.  -> *flag: device u32 inside the
+// index, != 0 after the stream is done if some item has no byte for its mark (then the index is not usable).
+int items_index_build(size_t nbytes, const uint64_t *off, size_t nitems, uint32_t trim, void *index, uint32_t **flag, void *stream) {
+    if (trim > 1 || !nitems || !nbytes) return (int)hipErrorInvalidValue;
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t stripe = items_stripe(nbytes);
+    const size_t nstripes = (nbytes + stripe - 1) / stripe;
+    uint32_t *ends = static_cast<uint32_t *>(index);
+    uint32_t *fl = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(index) + items_ends_bytes(nbytes));
+    uint64_t *base = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(fl) + 256);
+    *flag = fl;
+    hipError_t e = hipMemsetAsync(ends, 0, items_ends_bytes(nbytes) + 256, st);       // bitmap and flag
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(item_ends_kernel, dim3((unsigned)((nitems + kEndsItems - 1) / kEndsItems)), dim3(256), 0, st, off, nitems, trim, ends, fl);
+    hipLaunchKernelGGL(item_stripe_base_kernel, dim3((unsigned)((nstripes + 1 + 255) / 256)), dim3(256), 0, st, off, nitems, stripe, nstripes, base);
+    return (int)hipGetLastError();
+}
+// one byte per item into `accept` (16-byte aligned); `result` = items_result_bytes(nitems) of scratch
+int items_match(const LineDfaDevice &p, const uint8_t *bytes, size_t nbytes, size_t nitems, uint32_t trim, const void *index, void *result,
+                uint8_t *accept, void *stream) {
     if (!p.wide || p.in_global || p.stride != (kItemColumns << p.rep_log2) || trim > 1 || !nitems || !nbytes) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
-    uint32_t stripe = 0;
-    (void)match_items_stripes_scratch(nbytes, nitems, &stripe);
+    const uint32_t stripe = items_stripe(nbytes);
     const size_t nstripes = (nbytes + stripe - 1) / stripe;
-    uint8_t *sp = static_cast<uint8_t *>(scratch);
-    uint32_t *ends = reinterpret_cast<uint32_t *>(sp);                sp += items_align(((nbytes + 31) / 32 + 4) * 4);
-    uint32_t *flag = reinterpret_cast<uint32_t *>(sp);                sp += 256;
-    uint32_t *counts = reinterpret_cast<uint32_t *>(sp);              sp += items_align((nstripes + 1) * 4);
-    uint64_t *base = reinterpret_cast<uint64_t *>(sp);                sp += items_align((nstripes + 1 + scan_scratch_words(nstripes)) * 8);
-    uint32_t *bits = reinterpret_cast<uint32_t *>(sp);
-    *degenerate = flag;
-    hipError_t e = hipMemsetAsync(ends, 0, items_align(((nbytes + 31) / 32 + 4) * 4) + 256, st);       // bitmap and flag
-    if (e == hipSuccess) e = hipMemsetAsync(bits, 0, ((nitems + 31) / 32 + 4) * 4, st);
+    const uint32_t *ends = static_cast<const uint32_t *>(index);
+    const uint64_t *base = reinterpret_cast<const uint64_t *>(static_cast<const uint8_t *>(index) + items_ends_bytes(nbytes) + 256);
+    uint32_t *bits = static_cast<uint32_t *>(result);
+    hipError_t e = hipMemsetAsync(bits, 0, ((nitems + 31) / 32 + 4) * 4, st);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(item_ends_kernel, dim3((unsigned)((nitems + kEndsItems - 1) / kEndsItems)), dim3(256), 0, st, off, nitems, trim, ends, flag);
-    hipLaunchKernelGGL(item_stripe_base_kernel, dim3((unsigned)((nstripes + 1 + 255) / 256)), dim3(256), 0, st, off, nitems, stripe, nstripes, base);
-    (void)counts;
-    int rc = 0;
     const size_t table_bytes = LineDfaEngine<true, false>::lds_bytes(p);
     const uint32_t stage_off = (uint32_t)((table_bytes + 15) & ~(size_t)15);
     const size_t half_cu = 80 * 1024;
@@ -1348,7 +1355,7 @@ int match_items_stripes_dfa(const LineDfaDevice &p, const uint8_t *bytes, size_t
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(match_items_stripes_kernel<2>, dim3((unsigned)blocks), dim3(kThreads), lds, st, p, bytes, nbytes, stripe, base, ends, bits, stage_off, stage_words);
     }
-    rc = (int)hipGetLastError();
+    const int rc = (int)hipGetLastError();
     if (rc) return rc;
     return expand_bits(bits, nitems, accept, stream);
 }

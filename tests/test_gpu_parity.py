@@ -645,6 +645,19 @@ def test_explicit_items_stripe_wise():
         offs = torch.from_numpy(np.concatenate([[0], ends]).astype(np.int64)).cuda()
         dev = torch.from_numpy(text).cuda()
         assert torch.equal(r.match_extents(dev, offs, trim=trim), pieces(r, dev, offs, trim)), ("long items", trim)
+        # the same batch indexed once (rrx_items) and matched by several patterns
+        items = rr.Items(dev, offs, trim=trim)
+        assert items.num_items == len(lens) and items.stripe_wise
+        for pat in ("(a|b)*abb", "a*b*", "(ab|ba)*a?", "[^x]*"):
+            rp = rr.RRegex(pat)
+            assert torch.equal(rp.match_items(items), pieces(rp, dev, offs, trim)), ("items handle", pat, trim)
+        nfa = rr.RRegex("(a|b)*abb", rr.ENGINE_NFA)                     # an engine without the stripe-wise form: lane per item
+        assert torch.equal(nfa.match_items(items), pieces(r, dev, offs, trim))
+    # a batch with an empty item at trim 0 is indexed, found degenerate, and matched lane per item
+    o2 = torch.tensor([0, 3, 3, 8], dtype=torch.int64, device="cuda")
+    d2 = torch.from_numpy(np.frombuffer(b"abbaaabb", dtype=np.uint8).copy()).cuda()
+    it2 = rr.Items(d2, o2, trim=0)
+    assert not it2.stripe_wise and r.match_items(it2).tolist() == [1, 0, 1]
     # a pattern for which '\n' is an ordinary, matchable byte: same answers as on pieces
     host = synth.corpus("email", 4, n)
     dev = torch.from_numpy(host).cuda()

@@ -45,3 +45,15 @@ for w in ("url", "email"):
     torch.cuda.synchronize()
     t = (time.perf_counter() - t0) / 3
     print("%-6s %-20s items %9d  extents %8.1f GB/s  (%.2f ms)  trim 0" % (w, r.engine_name, off0.numel() - 1, d0.numel() / t / 1e9, t * 1e3), flush=True)
+    # indexed once (rrx_items), then matched: what a second, third ... pattern over the same column costs
+    for label, (dd, oo, tr) in (("trim 1", (dev, off, 1)), ("trim 0", (d0, off0, 0))):
+        items = rr.Items(dd, oo, trim=tr)
+        out = torch.empty(items.num_items, dtype=torch.uint8, device="cuda")
+        r.match_items(items, out=out)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            r.match_items(items, out=out)
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) / 5
+        print("%-6s %-20s items %9d  indexed  %8.1f GB/s  (%.2f ms)  %s  stripe-wise=%s" % (w, r.engine_name, items.num_items, dd.numel() / t / 1e9, t * 1e3, label, items.stripe_wise), flush=True)
