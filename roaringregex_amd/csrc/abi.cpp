@@ -888,7 +888,11 @@ int rrx_bitmap_to_bytes(int device, const uint32_t *d_bits, size_t nlines, uint8
     return RRX_OK;
 }
 
-static constexpr size_t kItemsStripesMin = (size_t)1 << 16, kItemsStripesMinBytes = (size_t)8 << 20;
+// below these a batch stays on the lane-per-item kernel (the index costs more than it saves); RRX_ITEMS_STRIPES_MIN=<items>
+// lowers both for tests and fuzzing (1: every batch goes stripe-wise)
+static size_t items_min_env() { const char *e = getenv("RRX_ITEMS_STRIPES_MIN"); return e ? (size_t)strtoull(e, nullptr, 10) : 0; }
+static const size_t kItemsStripesMin = items_min_env() ? items_min_env() : (size_t)1 << 16;
+static const size_t kItemsStripesMinBytes = items_min_env() ? items_min_env() : (size_t)8 << 20;
 int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, const uint64_t *d_off, size_t nitems, uint32_t trim,
                       uint8_t *d_accept, void *stream) {
     if (!re || (nitems && (!d_off || !d_accept))) return fail(RRX_ERR_ARG, "null argument");

@@ -110,6 +110,26 @@ while done < npat:
                     print("MISMATCH search_all", repr(p), "mix", mix, "cap", cap, "matches", int(ms.numel()), int(f2[-1]), flush=True)
                     sys.exit(1)
                 checked += 1
+    # explicit items: the lines as (offset, length) items, with their '\n' as the separator (trim 1) and squeezed together
+    # (trim 0, empty lines dropped); run with RRX_ITEMS_STRIPES_MIN=1 so that these small batches take the stripe-wise kernel
+    if len(arr) and arr[-1] == 10:
+        nlpos = np.nonzero(arr == 10)[0]
+        off1 = torch.from_numpy(np.concatenate([[0], nlpos + 1]).astype(np.int64)).cuda()
+        lens = np.diff(np.concatenate([[0], nlpos + 1])) - 1
+        nz = lens > 0
+        d0 = torch.from_numpy(arr[arr != 10].copy()).cuda()
+        off0 = torch.from_numpy(np.concatenate([[0], np.cumsum(lens[nz])]).astype(np.int64)).cuda()
+        for r_ in engines[:2]:
+            for label, (dd, oo, tr, ww) in (("trim 1", (dev, off1, 1, want)), ("trim 0", (d0, off0, 0, want[nz]))):
+                if oo.numel() < 2 or dd.numel() == 0:
+                    continue
+                got = r_.match_extents(dd, oo, trim=tr).cpu().numpy()
+                it = rr.Items(dd, oo, trim=tr)
+                got2 = r_.match_items(it).cpu().numpy()
+                if (got != ww).any() or (got2 != ww).any():
+                    print("MISMATCH items", repr(p), r_.engine_name, label, "mix", mix, "first bad", int(np.nonzero(got != ww)[0][:1].sum()), flush=True)
+                    sys.exit(1)
+                checked += 1
     # ONE long string (rrx_match_string: chunk maps by convergence on the table engine, chunk relations on the NFA engine)
     # against the oracle: random text, and an accepted line repeated (accepted as a whole by starred patterns)
     if done % 3 == 0:
