@@ -437,7 +437,10 @@ struct rrx_corpus {
     mutable void *d_all_scratch = nullptr;      // rrx_search_all: per-chunk status words, total, ticket (zeroed per call)
 };
 
-static constexpr size_t kLongStringBytes = 32 * 1024;   // shorter single strings stay on one lane
+static constexpr size_t kLongStringBytes = 32 * 1024;   // shorter single strings stay on one lane (NFA engines)
+// Table engines: the chunk maps by convergence cost a handful of short launches (60-80 us), a sequential lane 94 ns per byte
+// (tools/probe/facade_latency.py: 1.9 ms for 20 KB against 59 us; 130 us for 1 KB): from 1 KiB on the chunks win.
+static constexpr size_t kLongStringBytesTable = 1024;
 static constexpr uint32_t kLongNfaMaxBits = 256;        // NFA engines: chunk relations cost bytes x positions lane steps
 
 extern "C" {
@@ -1018,7 +1021,7 @@ int rrx_match_items(const rrx_regex *re, const rrx_items *it, uint8_t *d_accept,
 static int match_string_with(const rrx_regex *re, int device, const DeviceTables *t, const uint8_t *d_bytes, size_t nbytes, uint8_t *d_accept,
                              uint8_t *scratch, hipStream_t st) {
     const bool table_engine = re->engine == RRX_ENGINE_DFA;
-    if (table_engine && nbytes >= kLongStringBytes && t->dfa.nstates && t->dfa.nstates <= dev::kLongMaxStates) {
+    if (table_engine && nbytes >= kLongStringBytesTable && t->dfa.nstates && t->dfa.nstates <= dev::kLongMaxStates) {
         uint32_t chunk = 0;
         (void)dev::long_scratch_bytes(t->dfa.nstates, nbytes, &chunk);
         int le = dev::match_long_dfa(t->dfa, d_bytes, nbytes, chunk, scratch, d_accept, st);
@@ -1041,7 +1044,7 @@ static int match_string_with(const rrx_regex *re, int device, const DeviceTables
 }
 static size_t match_string_scratch_bytes(const rrx_regex *re, const DeviceTables *t, size_t nbytes) {
     const bool table_engine = re->engine == RRX_ENGINE_DFA;
-    if (table_engine && nbytes >= kLongStringBytes && t->dfa.nstates && t->dfa.nstates <= dev::kLongMaxStates) {
+    if (table_engine && nbytes >= kLongStringBytesTable && t->dfa.nstates && t->dfa.nstates <= dev::kLongMaxStates) {
         uint32_t chunk = 0;
         return dev::long_scratch_bytes(t->dfa.nstates, nbytes, &chunk);
     }

@@ -1245,8 +1245,10 @@ int search_all(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, const
     return (int)hipGetLastError();
 }
 static uint32_t long_chunk(size_t nbytes) {
-    uint32_t chunk = 1024;                                     // at most 65536 chunks, of 1 KiB or more
-    while (((nbytes + chunk - 1) / chunk) > 65536) chunk <<= 1;
+    // short strings: 256-byte chunks (a string of a few KiB is a handful of short launches, not one long sequential lane);
+    // from 256 KiB on chunks of 1 KiB or more, at most 65536 of them
+    uint32_t chunk = 256;
+    while (((nbytes + chunk - 1) / chunk) > (chunk < 1024 ? 1024u : 65536u)) chunk <<= 1;
     return chunk;
 }
 size_t long_scratch_bytes(uint32_t nstates, size_t nbytes, uint32_t *chunk) {

@@ -675,7 +675,7 @@ def test_one_long_string_is_stepped_in_parallel_chunks():
     rng = np.random.default_rng(21)
     ab = np.frombuffer(b"ab", dtype=np.uint8)
     cases = []
-    for n in (32 * 1024 - 1, 32 * 1024, 32 * 1024 + 1, 100_003, (1 << 20) + 17, 5 * (1 << 20) + 1023, 20 * (1 << 20) + 5):
+    for n in (1023, 1024, 1025, 2047, 2048, 2049, 3000, 8191, 32 * 1024 - 1, 32 * 1024, 32 * 1024 + 1, 100_003, 262143, 262145, (1 << 20) + 17, 5 * (1 << 20) + 1023, 20 * (1 << 20) + 5):
         body = ab[rng.integers(0, 2, size=n)]
         for tail in (b"abb", b"aba"):
             t = body.copy()
