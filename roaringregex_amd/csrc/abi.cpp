@@ -570,6 +570,17 @@ int rrx_corpus_create(int device, const void *d_bytes, size_t nbytes, void *stre
     return rrx_corpus_create_ex(device, d_bytes, nbytes, 0, stream, out);
 }
 
+// The size-based stripe suits lines of a few dozen bytes.  Every lane walks half a line past its stripe, so long lines
+// want longer stripes (a{1,300} config, 200 B per line, 1 GiB: 4 KiB stripes +14 % over 2 KiB): double the stripe while a
+// line is more than 1/16 of it.  Short lines want shorter stripes: a workgroup's 1024 lanes hold 1024 * stripe / avg_line
+// lines, and beyond the 131072 its LDS result window is sure to hold (16 KiB) the result words go to memory one atomic at
+// a time (k<n> lines of 5.4 bytes, 8 GiB: 4 KiB stripes 3.69 TB/s, 1 KiB stripes 4.53; profiles/r02_short_line_stripes.txt).
+static uint32_t stripe_for_lines(size_t nbytes, size_t avg_line) {
+    uint32_t want = dev::pick_stripe(nbytes);
+    while (want < dev::kMaxStripe && avg_line * 16 > want && nbytes / (2 * (size_t)want) >= ((size_t)1 << 17)) want *= 2;
+    while (want > dev::kMinStripe && (avg_line + 1) * 128 < want) want /= 2;
+    return want;
+}
 int rrx_corpus_create_ex(int device, const void *d_bytes, size_t nbytes, uint32_t stripe_bytes, void *stream, rrx_corpus **out) {
     if (!out || (nbytes && !d_bytes)) return fail(RRX_ERR_ARG, "null argument");
     if (stripe_bytes && (stripe_bytes < dev::kMinStripe || stripe_bytes > dev::kMaxStripe || (stripe_bytes & (stripe_bytes - 1))))
@@ -582,6 +593,16 @@ int rrx_corpus_create_ex(int device, const void *d_bytes, size_t nbytes, uint32_
     c->d_bytes = static_cast<const uint8_t *>(d_bytes);
     c->nbytes = nbytes;
     c->stripe = stripe_bytes ? stripe_bytes : dev::pick_stripe(nbytes);
+    // automatic choice on a large corpus: the line length is taken from its first 4 MiB first (two small launches), so
+    // that a corpus of very short or very long lines is indexed once, not twice (the check below still stands)
+    constexpr size_t kSample = (size_t)4 << 20;
+    if (!stripe_bytes && nbytes >= 16 * kSample) {
+        rrx_corpus *sample = nullptr;
+        if (rrx_corpus_create_ex(device, d_bytes, kSample, dev::pick_stripe(kSample), stream, &sample) == RRX_OK && sample) {
+            if (sample->nlines) c->stripe = stripe_for_lines(nbytes, kSample / sample->nlines);
+            rrx_corpus_free(sample);
+        }
+    }
     c->nstripes = (nbytes + c->stripe - 1) / c->stripe;
     hipError_t e = hipMalloc(reinterpret_cast<void **>(&c->d_counts), (c->nstripes + 1) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void **>(&c->d_base), (c->nstripes + 1 + dev::scan_scratch_words(c->nstripes)) * sizeof(uint64_t));
@@ -602,17 +623,9 @@ int rrx_corpus_create_ex(int device, const void *d_bytes, size_t nbytes, uint32_
     if (e != hipSuccess) { rrx_corpus_free(c); return hip_fail(e, "line index readback"); }
     c->has_high = (flags & 1u) != 0;
     c->nlines = (size_t)total + ((nbytes && last != '\n') ? 1 : 0);
-    // The size-based stripe suits lines of a few dozen bytes.  Every lane walks half a line past its stripe, so long
-    // lines want longer stripes (a{1,300} config, 200 B per line, 1 GiB: 4 KiB stripes +14 % over 2 KiB): with the
-    // line count known, double the stripe while a line is more than 1/16 of it, and index once more.
+    // with the line count known: the stripe this corpus wants (stripe_for_lines); if it is another one, index once more
     if (!stripe_bytes && c->nlines) {
-        const size_t avg_line = nbytes / c->nlines;
-        uint32_t want = c->stripe;
-        while (want < dev::kMaxStripe && avg_line * 16 > want && nbytes / (2 * (size_t)want) >= ((size_t)1 << 17)) want *= 2;
-        // Short lines want shorter stripes: a workgroup's 1024 lanes hold 1024 * stripe / avg_line lines, and beyond the
-        // 131072 its LDS result window is sure to hold (16 KiB) the result words go to memory one atomic at a time
-        // (k<n> lines of 5.4 bytes, 8 GiB: 4 KiB stripes 3.69 TB/s, 1 KiB stripes 4.53; profiles/r02_short_line_stripes.txt).
-        while (want > dev::kMinStripe && (avg_line + 1) * 128 < want) want /= 2;
+        const uint32_t want = stripe_for_lines(nbytes, nbytes / c->nlines);
         if (want != c->stripe) {
             rrx_corpus_free(c);
             return rrx_corpus_create_ex(device, d_bytes, nbytes, want, stream, out);
