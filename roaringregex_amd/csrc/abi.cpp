@@ -909,6 +909,16 @@ int rrx_bitmap_to_bytes(int device, const uint32_t *d_bits, size_t nlines, uint8
 static size_t items_min_env() { const char *e = getenv("RRX_ITEMS_STRIPES_MIN"); return e ? (size_t)strtoull(e, nullptr, 10) : 0; }
 static const size_t kItemsStripesMin = items_min_env() ? items_min_env() : (size_t)1 << 16;
 static const size_t kItemsStripesMinBytes = items_min_env() ? items_min_env() : (size_t)8 << 20;
+// a lane (lane group, workgroup) per item
+static int match_extents_lanes(const rrx_regex *re, const DeviceTables *t, const uint8_t *b, const uint64_t *d_off, size_t nitems, uint32_t trim,
+                               uint8_t *d_accept, void *stream) {
+    int e = re->engine == RRX_ENGINE_NFA_BLOCK ? dev::match_extents_block_nfa(t->block, b, d_off, nitems, trim, d_accept, stream)
+            : re->engine == RRX_ENGINE_NFA_WAVE ? dev::match_extents_group_nfa(t->group, b, d_off, nitems, trim, d_accept, stream)
+            : re->engine == RRX_ENGINE_NFA ? dev::match_extents_nfa(t->nfa, b, d_off, nitems, trim, d_accept, stream)
+                                         : dev::match_extents_dfa(t->dfa, b, d_off, nitems, trim, d_accept, stream);
+    if (e) return hip_fail((hipError_t)e, "match_extents launch");
+    return RRX_OK;
+}
 int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, const uint64_t *d_off, size_t nitems, uint32_t trim,
                       uint8_t *d_accept, void *stream) {
     if (!re || (nitems && (!d_off || !d_accept))) return fail(RRX_ERR_ARG, "null argument");
@@ -948,12 +958,7 @@ int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, cons
             if (!degenerate) return RRX_OK;
         }
     }
-    int e = re->engine == RRX_ENGINE_NFA_BLOCK ? dev::match_extents_block_nfa(t->block, b, d_off, nitems, trim, d_accept, stream)
-            : re->engine == RRX_ENGINE_NFA_WAVE ? dev::match_extents_group_nfa(t->group, b, d_off, nitems, trim, d_accept, stream)
-            : re->engine == RRX_ENGINE_NFA ? dev::match_extents_nfa(t->nfa, b, d_off, nitems, trim, d_accept, stream)
-                                         : dev::match_extents_dfa(t->dfa, b, d_off, nitems, trim, d_accept, stream);
-    if (e) return hip_fail((hipError_t)e, "match_extents launch");
-    return RRX_OK;
+    return match_extents_lanes(re, t, b, d_off, nitems, trim, d_accept, stream);
 }
 
 // A batch of items indexed once (item-end bitmap + stripe base), matched by many patterns: rrx_corpus' counterpart for an
@@ -1013,19 +1018,20 @@ void rrx_items_free(rrx_items *it) {
 int rrx_match_items(const rrx_regex *re, const rrx_items *it, uint8_t *d_accept, void *stream) {
     if (!re || !it || (it->nitems && !d_accept)) return fail(RRX_ERR_ARG, "null argument");
     if (!it->nitems) return RRX_OK;
+    const DeviceTables *t;
+    int rc = re->tables(it->device, &t);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(it->device));
     if (it->stripes && re->engine == RRX_ENGINE_DFA && !(reinterpret_cast<uintptr_t>(d_accept) & 15)) {
-        const DeviceTables *t;
-        int rc = re->tables(it->device, &t);
-        if (rc) return rc;
         if (const dev::LineDfaDevice *items = re->items_table(it->device)) {
-            HIP_TRY(hipSetDevice(it->device));
             std::lock_guard<std::mutex> lock(it->mu);
             int le = dev::items_match(*items, it->d_bytes + it->first, it->nbytes, it->nitems, it->trim, it->d_index, it->d_result, d_accept, stream);
             if (le) return hip_fail((hipError_t)le, "match_items launch");
             return RRX_OK;
         }
     }
-    return rrx_match_extents(re, it->device, it->d_bytes, it->d_off, it->nitems, it->trim, d_accept, stream);
+    // the batch or the pattern does not admit the stripe-wise kernel (the index said so once: no second attempt)
+    return match_extents_lanes(re, t, it->d_bytes, it->d_off, it->nitems, it->trim, d_accept, stream);
 }
 
 // One device-resident string of any length.  Long strings take the chunk-map path when the automaton has a small
