@@ -570,17 +570,6 @@ int rrx_corpus_create(int device, const void *d_bytes, size_t nbytes, void *stre
     return rrx_corpus_create_ex(device, d_bytes, nbytes, 0, stream, out);
 }
 
-// The size-based stripe suits lines of a few dozen bytes.  Every lane walks half a line past its stripe, so long lines
-// want longer stripes (a{1,300} config, 200 B per line, 1 GiB: 4 KiB stripes +14 % over 2 KiB): double the stripe while a
-// line is more than 1/16 of it.  Short lines want shorter stripes: a workgroup's 1024 lanes hold 1024 * stripe / avg_line
-// lines, and beyond the 131072 its LDS result window is sure to hold (16 KiB) the result words go to memory one atomic at
-// a time (k<n> lines of 5.4 bytes, 8 GiB: 4 KiB stripes 3.69 TB/s, 1 KiB stripes 4.53; profiles/r02_short_line_stripes.txt).
-static uint32_t stripe_for_lines(size_t nbytes, size_t avg_line) {
-    uint32_t want = dev::pick_stripe(nbytes);
-    while (want < dev::kMaxStripe && avg_line * 16 > want && nbytes / (2 * (size_t)want) >= ((size_t)1 << 17)) want *= 2;
-    while (want > dev::kMinStripe && (avg_line + 1) * 128 < want) want /= 2;
-    return want;
-}
 int rrx_corpus_create_ex(int device, const void *d_bytes, size_t nbytes, uint32_t stripe_bytes, void *stream, rrx_corpus **out) {
     if (!out || (nbytes && !d_bytes)) return fail(RRX_ERR_ARG, "null argument");
     if (stripe_bytes && (stripe_bytes < dev::kMinStripe || stripe_bytes > dev::kMaxStripe || (stripe_bytes & (stripe_bytes - 1))))
@@ -599,7 +588,7 @@ int rrx_corpus_create_ex(int device, const void *d_bytes, size_t nbytes, uint32_
     if (!stripe_bytes && nbytes >= 16 * kSample) {
         rrx_corpus *sample = nullptr;
         if (rrx_corpus_create_ex(device, d_bytes, kSample, dev::pick_stripe(kSample), stream, &sample) == RRX_OK && sample) {
-            if (sample->nlines) c->stripe = stripe_for_lines(nbytes, kSample / sample->nlines);
+            if (sample->nlines) c->stripe = dev::stripe_for_lines(nbytes, kSample / sample->nlines);
             rrx_corpus_free(sample);
         }
     }
@@ -625,7 +614,7 @@ int rrx_corpus_create_ex(int device, const void *d_bytes, size_t nbytes, uint32_
     c->nlines = (size_t)total + ((nbytes && last != '\n') ? 1 : 0);
     // with the line count known: the stripe this corpus wants (stripe_for_lines); if it is another one, index once more
     if (!stripe_bytes && c->nlines) {
-        const uint32_t want = stripe_for_lines(nbytes, nbytes / c->nlines);
+        const uint32_t want = dev::stripe_for_lines(nbytes, nbytes / c->nlines);
         if (want != c->stripe) {
             rrx_corpus_free(c);
             return rrx_corpus_create_ex(device, d_bytes, nbytes, want, stream, out);
@@ -945,7 +934,7 @@ int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, cons
             const size_t nbytes = (size_t)(last - first);
             std::lock_guard<std::mutex> lock(re->onepass_mu);
             void *buf = nullptr;
-            const size_t ib = dev::items_index_bytes(nbytes);
+            const size_t ib = dev::items_index_bytes(nbytes, nitems);
             rc = re->onepass_for(device, ib + dev::items_result_bytes(nitems), &buf);
             if (rc) return rc;
             uint32_t *d_flag = nullptr;
@@ -992,7 +981,7 @@ int rrx_items_create(int device, const void *d_bytes, const uint64_t *d_off, siz
         it->first = first;
         if (last > first && !(reinterpret_cast<uintptr_t>(it->d_bytes + first) & 15)) {
             it->nbytes = (size_t)(last - first);
-            e = hipMalloc(&it->d_index, dev::items_index_bytes(it->nbytes));
+            e = hipMalloc(&it->d_index, dev::items_index_bytes(it->nbytes, nitems));
             if (e == hipSuccess) e = hipMalloc(&it->d_result, dev::items_result_bytes(nitems));
             if (e != hipSuccess) { rrx_items_free(it); return hip_fail(e, "hipMalloc(items index)"); }
             uint32_t *d_flag = nullptr;

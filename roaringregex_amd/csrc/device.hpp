@@ -24,6 +24,17 @@ inline uint32_t pick_stripe(size_t nbytes) {
     while (s < kMaxStripe && nbytes / s > kTargetLanes) s *= 2;
     return s;
 }
+// The size-based stripe suits lines of a few dozen bytes.  Every lane walks half a line past its stripe, so long lines
+// want longer stripes (a{1,300} config, 200 B per line, 1 GiB: 4 KiB stripes +14 % over 2 KiB): double the stripe while a
+// line is more than 1/16 of it.  Short lines want shorter stripes: a workgroup's 1024 lanes hold 1024 * stripe / avg_line
+// lines, and beyond the 131072 its LDS result window is sure to hold (16 KiB) the result words go to memory one atomic at
+// a time (k<n> lines of 5.4 bytes, 8 GiB: 4 KiB stripes 3.69 TB/s, 1 KiB stripes 4.53; profiles/r02_short_line_stripes.txt).
+inline uint32_t stripe_for_lines(size_t nbytes, size_t avg_line) {
+    uint32_t want = pick_stripe(nbytes);
+    while (want < kMaxStripe && avg_line * 16 > want && nbytes / (2 * (size_t)want) >= ((size_t)1 << 17)) want *= 2;
+    while (want > kMinStripe && (avg_line + 1) * 128 < want) want /= 2;
+    return want;
+}
 constexpr int kRound = 128;                      // one whole cache line per lane per round
 constexpr int kMaxNfaWords = 16;                 // 512 positions per lane-resident state set
 constexpr uint32_t kWideColumns = 129;           // columns 0..127 = byte values, 128 = any byte >= 0x80
@@ -214,7 +225,7 @@ constexpr uint32_t kLongGroup = 128;             // maps composed per workgroup 
 // explicit items (an offsets array over one buffer) stripe-wise: see kernels_table.hip.  The table is the plain one in the
 // wide line-table format with kItemColumns columns: byte values 0..127, 128 = any byte >= 0x80, kItemEndColumn = end of item
 constexpr uint32_t kItemColumns = 131, kItemEndColumn = 129;      // (130 in use, 131 keeps the row stride odd)
-size_t items_index_bytes(size_t nbytes);                 // item-end bitmap, flag, stripe base
+size_t items_index_bytes(size_t nbytes, size_t nitems);  // item-end bitmap, flag, stripe base
 size_t items_result_bytes(size_t nitems);                // result bitmap of one match
 int items_index_build(size_t nbytes, const uint64_t *off, size_t nitems, uint32_t trim, void *index, uint32_t **flag, void *stream);
 int items_match(const LineDfaDevice &p, const uint8_t *bytes, size_t nbytes, size_t nitems, uint32_t trim, const void *index, void *result,

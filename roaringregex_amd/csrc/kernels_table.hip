@@ -1305,9 +1305,10 @@ int match_long_dfa(const DfaDevice &p, const uint8_t *bytes, size_t nbytes, uint
 // and, per match, a result bitmap of nitems bits.
 static size_t items_align(size_t x) { return (x + 255) & ~(size_t)255; }
 static size_t items_ends_bytes(size_t nbytes) { return items_align(((nbytes + 31) / 32 + 4) * 4); }
-uint32_t items_stripe(size_t nbytes) { return pick_stripe(nbytes); }
-size_t items_index_bytes(size_t nbytes) {
-    const size_t nstripes = (nbytes + items_stripe(nbytes) - 1) / items_stripe(nbytes);
+// the stripe an items batch wants: by its size and its mean item length, like a corpus (stripe_for_lines)
+static uint32_t items_stripe(size_t nbytes, size_t nitems) { return stripe_for_lines(nbytes, nitems ? nbytes / nitems : nbytes); }
+size_t items_index_bytes(size_t nbytes, size_t nitems) {
+    const size_t nstripes = (nbytes + items_stripe(nbytes, nitems) - 1) / items_stripe(nbytes, nitems);
     return items_ends_bytes(nbytes) + 256 + items_align((nstripes + 1) * 8);
 }
 size_t items_result_bytes(size_t nitems) { return items_align(((nitems + 31) / 32 + 4) * 4); }
@@ -1316,7 +1317,7 @@ size_t items_result_bytes(size_t nitems) { return items_align(((nitems + 31) / 3
 int items_index_build(size_t nbytes, const uint64_t *off, size_t nitems, uint32_t trim, void *index, uint32_t **flag, void *stream) {
     if (trim > 1 || !nitems || !nbytes) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
-    const uint32_t stripe = items_stripe(nbytes);
+    const uint32_t stripe = items_stripe(nbytes, nitems);
     const size_t nstripes = (nbytes + stripe - 1) / stripe;
     uint32_t *ends = static_cast<uint32_t *>(index);
     uint32_t *fl = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(index) + items_ends_bytes(nbytes));
@@ -1333,7 +1334,7 @@ int items_match(const LineDfaDevice &p, const uint8_t *bytes, size_t nbytes, siz
                 uint8_t *accept, void *stream) {
     if (!p.wide || p.in_global || p.stride != (kItemColumns << p.rep_log2) || trim > 1 || !nitems || !nbytes) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
-    const uint32_t stripe = items_stripe(nbytes);
+    const uint32_t stripe = items_stripe(nbytes, nitems);
     const size_t nstripes = (nbytes + stripe - 1) / stripe;
     const uint32_t *ends = static_cast<const uint32_t *>(index);
     const uint64_t *base = reinterpret_cast<const uint64_t *>(static_cast<const uint8_t *>(index) + items_ends_bytes(nbytes) + 256);
