@@ -835,7 +835,7 @@ __global__ __launch_bounds__(kThreads) void match_items_stripes_kernel(LineDfaDe
         // a text word (no byte >= 0x81 in it) with the end bits m4 of its four bytes
         auto word = [&](uint32_t w, uint32_t m4) {
             if constexpr (ENDS == 1) {
-                if (__builtin_amdgcn_ballot_w64(m4 != 0)) {
+                {   // (no test for "some lane has a separator in this word": with 64 lanes it is nearly always so)
                     // bit k of m4 -> byte k (24-bit multiply: v_mul_lo_u32 runs at a quarter of the rate)
                     const uint32_t t = __umul24(m4, 0x00204081u) & 0x01010101u;
                     const uint32_t bm = (t << 8) - t;
