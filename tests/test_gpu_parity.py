@@ -439,6 +439,179 @@ def test_wave_cooperative_engine_on_large_automata():
         assert (r.get_acceptance_iter(t).advance().value() is not None) == o.accepts(t)
 
 
+def _coop_engine_case(pattern, engine, engine_name, lengths, seed, alphabet="ab", stripes=STRIPES, per_length=2, facade=4,
+                      boundary_lines=12, boundary_deltas=(-1, 0, 1)):
+    """One cooperative-engine build against the ORACLE through every entry: the batch kernel at several stripe sizes on a
+    ragged corpus with and without a final '\n', a corpus whose line ends sit exactly on stripe boundaries (+-1), the
+    one-shot entry (two passes for these engines), explicit items, and the iterator facade."""
+    rng = random.Random(seed)
+    r = rr.RRegex(pattern, engine)
+    assert r.engine_name == engine_name, (pattern[:30], r.engine_name)
+    o = OracleRegex(pattern)
+    lines = []
+    for n in lengths:
+        for _ in range(per_length):
+            lines.append("".join(rng.choice(alphabet) for _ in range(n)))
+        lines.append(alphabet[0] * n)
+        lines.append(alphabet[-1] * n)
+    want_of = {}
+
+    def want(t):
+        if t not in want_of:
+            want_of[t] = int(o.accepts(t))
+        return want_of[t]
+
+    expect = np.array([want(t) for t in lines], dtype=np.uint8)
+    assert 0 < expect.sum() < len(expect), (pattern[:30], int(expect.sum()), len(expect))
+    for tail in ("", "\n"):
+        data = np.frombuffer(("\n".join(lines) + tail).encode("latin-1"), dtype=np.uint8)
+        dev = torch.from_numpy(data.copy()).cuda()
+        for stripe in stripes:
+            corpus = rr.Corpus(dev, stripe=stripe)
+            assert corpus.num_lines == len(lines)
+            got = r.match_corpus(corpus).cpu().numpy()
+            bad = np.nonzero(got != expect)[0]
+            assert bad.size == 0, (pattern[:30], engine_name, "stripe", stripe, "tail", repr(tail), "first bad line", int(bad[0]), len(lines[int(bad[0])]))
+        bits, nlines = r.match_device_bits(dev)
+        assert nlines == len(lines) and (_bits_to_bytes(bits, nlines) == expect).all(), (pattern[:30], "one-shot entry")
+    # line ends exactly on / next to stripe boundaries: the same line texts re-cut so that every '\n' sits at k*stripe + d
+    for stripe in stripes[:2]:
+        for d in boundary_deltas:
+            parts, texts, pos = [], [], 0
+            for t in lines:
+                if not t or len(texts) >= boundary_lines:
+                    continue
+                end = pos + len(t)                              # where this line's '\n' would fall
+                target = ((end + stripe - 1) // stripe) * stripe + d
+                pad = target - end
+                if pad < 0:
+                    pad += stripe
+                t2 = t + alphabet[-1] * pad
+                texts.append(t2)
+                parts.append(t2)
+                pos += len(t2) + 1
+                if pos > 40 * stripe:
+                    break
+            data = np.frombuffer(("\n".join(parts) + "\n").encode("latin-1"), dtype=np.uint8)
+            exp2 = np.array([want(t) for t in texts], dtype=np.uint8)
+            got = r.match_corpus(rr.Corpus(torch.from_numpy(data.copy()).cuda(), stripe=stripe)).cpu().numpy()
+            assert (got == exp2).all(), (pattern[:30], engine_name, "boundary cut", stripe, d)
+    off = np.cumsum([0] + [len(t) for t in lines]).astype(np.int64)
+    blob = np.frombuffer("".join(lines).encode("latin-1"), dtype=np.uint8)
+    blob = torch.from_numpy(blob.copy()).cuda() if len(blob) else torch.empty(0, dtype=torch.uint8, device="cuda")
+    got = r.match_extents(blob, torch.from_numpy(off).cuda()).cpu().numpy()
+    assert (got == expect).all(), (pattern[:30], engine_name, "extents")
+    for t in lines[:facade]:
+        assert (r.get_acceptance_iter(t).advance().value() is not None) == bool(want(t)), (pattern[:30], "facade", len(t))
+
+
+def test_group_engine_32_and_64_lanes_per_string():
+    """match_stripes_group_kernel<32> (1025-2048 positions: two strings per wave, wave_shr:1 carries a word across a DPP
+    row boundary) and <64> (2049-4096: one string per wave), with their extents forms - never launched before round 3.
+    Reference: any automaton size, Parser.cpp:165; the loop, NFA.cc:77-85."""
+    _coop_engine_case("(a|b)*a(a|b){1500}", rr.ENGINE_AUTO, "nfa-group-cooperative", (0, 1, 1500, 1501, 1502, 1503, 1600, 2100, 3300, 5000), 31)
+    assert rr.RRegex("(a|b)*a(a|b){1500}").words_per_set == 47
+    _coop_engine_case("(a|b)*a(a|b){3000}", rr.ENGINE_AUTO, "nfa-group-cooperative", (0, 2, 3000, 3001, 3002, 3003, 3100, 4200, 6100, 9000), 32)
+    assert rr.RRegex("(a|b)*a(a|b){3000}").words_per_set == 94
+    # exception edges reaching across lanes and rows of the group (not just the add-one chain)
+    _coop_engine_case("((a|b)*a(a|b){700}c|(b|c)*b(b|c){800}a)*", rr.ENGINE_NFA_WAVE, "nfa-group-cooperative",
+                      (0, 3, 702, 703, 802, 803, 1505, 1506, 2207, 2400), 33, alphabet="abc", stripes=(1024, 16384), facade=2)
+
+
+def test_block_engine_512_lanes():
+    """match_stripes_block_kernel at T = 512 (16385-32768 positions: 8 waves, the [2][T] / [2][2T] LDS exchange at twice
+    the size) - never launched before round 3."""
+    p = "(a|b)*a.{17000}"
+    assert rr.RRegex(p).words_per_set == 532
+    _coop_engine_case(p, rr.ENGINE_AUTO, "nfa-block-cooperative", (0, 17001, 17002, 17003, 21000), 34,
+                      stripes=(1024, 16384), per_length=1, facade=3, boundary_lines=3, boundary_deltas=(0,))
+
+
+def test_small_automata_forced_onto_the_cooperative_engines():
+    """a{1,300} (BASELINE configs[3]: 301 positions, a pure chain) forced onto the group and block engines over the synthetic
+    `arepeat` corpus - batch entry and one-shot entry - and U2 / the email pattern likewise (exception edges, byte
+    classes): bit-identical to the oracle."""
+    import synth
+    for kind, pattern, nbytes in (("arepeat", "a{1,300}", 192 << 10), ("url", U2, 96 << 10), ("email", EMAIL, 64 << 10)):
+        data = synth.corpus(kind, 17, nbytes)
+        want = OracleRegex(pattern).match_lines(data)
+        dev = torch.from_numpy(data.copy()).cuda()
+        for e in (rr.ENGINE_NFA_WAVE, rr.ENGINE_NFA_BLOCK):
+            r = rr.RRegex(pattern, e)
+            for stripe in (0, 1024, 16384):
+                got = r.match_corpus(rr.Corpus(dev, stripe=stripe)).cpu().numpy()
+                bad = np.nonzero(got != want)[0]
+                assert bad.size == 0, (kind, r.engine_name, stripe, "first bad line", int(bad[0]))
+            bits, nlines = r.match_device_bits(dev)
+            assert nlines == len(want) and (_bits_to_bytes(bits, nlines) == want).all(), (kind, r.engine_name, "one-shot")
+
+
+def test_nfa_lane_engine_sixteen_words():
+    """LineNfaEngine<16, ...> (385-512 positions in one lane's registers), all four builds: bare chain, + self loops and
+    add-carry groups, + exception rows - never launched before round 3.  Batch, one-shot, extents, facade vs the oracle."""
+    cases = [("a{1,450}", (0, 1, 2, 449, 450, 451, 452, 700), "a"),
+             ("(a|b)*a(a|b){400}", (0, 1, 400, 401, 402, 403, 500, 900, 1700), "ab"),
+             ("(ab|ba){1,120}", (0, 2, 3, 100, 238, 240, 242, 480), "ab"),
+             ("b*a{1,440}", (0, 1, 5, 440, 441, 445, 600), "ab")]
+    for pattern, lengths, alphabet in cases:
+        r = rr.RRegex(pattern, rr.ENGINE_NFA)
+        assert 13 <= r.words_per_set <= 16, (pattern, r.words_per_set)
+        rng = random.Random(len(pattern))
+        o = OracleRegex(pattern)
+        lines = []
+        for n in lengths:
+            lines += ["".join(rng.choice(alphabet) for _ in range(n)) for _ in range(3)]
+            lines += [alphabet[0] * n, (alphabet[-1] + alphabet[0] * n)[:max(n, 1)], ("ab" * n)[:n], ("ba" * n)[:n]]
+        lines += ["".join(rng.choice(alphabet) for _ in range(rng.choice([3, 17, 60, 130]))) for _ in range(3000)]
+        want = np.array([int(o.accepts(t)) for t in lines], dtype=np.uint8)
+        assert 0 < want.sum() < len(want), pattern
+        for tail in ("\n", ""):
+            data = np.frombuffer(("\n".join(lines) + tail).encode(), dtype=np.uint8)
+            dev = torch.from_numpy(data.copy()).cuda()
+            for stripe in STRIPES:
+                got = r.match_corpus(rr.Corpus(dev, stripe=stripe)).cpu().numpy()
+                bad = np.nonzero(got != want)[0]
+                assert bad.size == 0, (pattern, "stripe", stripe, "first bad line", int(bad[0]), len(lines[int(bad[0])]))
+            bits, nlines = r.match_device_bits(dev)
+            assert nlines == len(want) and (_bits_to_bytes(bits, nlines) == want).all(), (pattern, "one-shot")
+        off = np.cumsum([0] + [len(t) for t in lines]).astype(np.int64)
+        blob = torch.from_numpy(np.frombuffer("".join(lines).encode(), dtype=np.uint8).copy()).cuda()
+        got = r.match_extents(blob, torch.from_numpy(off).cuda()).cpu().numpy()
+        assert (got == want).all(), (pattern, "extents")
+        for t in lines[:8]:
+            assert (r.get_acceptance_iter(t).advance().value() is not None) == o.accepts(t)
+
+
+def test_stripe_wise_items_against_the_oracle():
+    """match_items_stripes_kernel (item ends from a bitmap, the plain table with an END OF ITEM column) checked directly
+    against the ORACLE, item by item: an indexed batch (rrx_items) always takes the stripe-wise kernel, whatever its
+    size.  trim 0 and 1, separators of any value, items longer than a stripe, 0x00 and bytes >= 0x80, '\n' inside items."""
+    rng = np.random.default_rng(41)
+    for pattern, alphabet in (("(a|b)*abb", b"ab"), ("(a|b|\n)*ab(a|\n)*", b"ab\n"), (EMAIL, b"ab1.@_Z")):
+        o = OracleRegex(pattern.replace("\n", "x")) if "\n" in pattern else OracleRegex(pattern)
+        r = rr.RRegex(pattern)
+        assert r.engine == rr.ENGINE_DFA
+        for trim in (0, 1):
+            lens = rng.choice([1, 2, 3, 7, 19, 64, 300, 5000, 40_000], size=6000, p=[0.15, 0.15, 0.15, 0.2, 0.2, 0.1, 0.04, 0.009, 0.001])
+            tot = int(lens.sum()) + trim * len(lens)
+            text = np.frombuffer(alphabet, dtype=np.uint8)[rng.integers(0, len(alphabet), size=tot)].copy()
+            dirty = rng.integers(0, tot, size=40)
+            text[dirty] = rng.choice(np.array([0x00, 0x80, 0xff], dtype=np.uint8), size=len(dirty))
+            ends = np.cumsum(lens + trim)
+            if trim:
+                text[ends - 1] = np.frombuffer(b"ab\n;\x00\xff", dtype=np.uint8)[rng.integers(0, 6, size=len(lens))]
+            offs = np.concatenate([[0], ends]).astype(np.int64)
+            items = rr.Items(torch.from_numpy(text).cuda(), torch.from_numpy(offs).cuda(), trim=trim)
+            assert items.stripe_wise
+            got = r.match_items(items).cpu().numpy()
+            raw = text.tobytes()
+            want = np.array([int(o.accepts(raw[offs[i]:offs[i + 1] - trim].replace(b"\n", b"x") if "\n" in pattern else raw[offs[i]:offs[i + 1] - trim]))
+                             for i in range(len(lens))], dtype=np.uint8)
+            bad = np.nonzero(got != want)[0]
+            assert bad.size == 0, (pattern[:20], "trim", trim, "first bad item", int(bad[0]), int(lens[bad[0]]))
+            assert 0 < want.sum() < len(want)
+
+
 def _bits_to_bytes(words, n):
     w = words.cpu().numpy().view(np.uint32)
     return ((w[:, None] >> np.arange(32, dtype=np.uint32)[None, :]) & 1).astype(np.uint8).reshape(-1)[:n]
