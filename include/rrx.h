@@ -85,7 +85,9 @@ int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accep
 /* The same for a device-resident buffer that has no rrx_corpus yet, in ONE call: with the lane engines (tables, NFA) the
  * text is read once (the newline index is a by-product of the match: per-stripe counts, a scan, a compaction of the
  * lanes' verdict streams); the cooperative engines build the index first.  d_accept_bits holds cap_words words (zeroed and
- * filled on `stream`); *nlines = number of strings; RRX_ERR_ARG if the bitmap is too small.  Synchronous.           */
+ * filled on `stream`); *nlines = number of strings; RRX_ERR_ARG if the bitmap is too small.  Synchronous (the line count
+ * comes back through pinned memory: one wait, no copies).  The regex handle keeps the scratch of its largest call until
+ * rrx_free: 12 bytes per stripe + the lanes' verdict streams, worst case 1 bit per byte of text (one line per byte).   */
 int rrx_match_device(const rrx_regex *re, int device, const void *d_bytes, size_t nbytes, uint32_t *d_accept_bits,
                      size_t cap_words, size_t *nlines, void *stream);
 /* One byte per string (0/1) from the bitmap; d_accept holds nlines bytes, 16-byte aligned.                  */
@@ -113,7 +115,10 @@ int rrx_search_all_fill(const rrx_regex *re, const rrx_corpus *corpus, const uin
 int rrx_search_all(const rrx_regex *re, const rrx_corpus *corpus, uint64_t *d_first, uint32_t *d_start, uint32_t *d_end,
                    size_t cap, size_t *total, void *stream);
 
-/* explicit extents: item i = d_bytes[d_off[i] .. d_off[i+1] - trim); '\n' is an ordinary character here */
+/* explicit extents: item i = d_bytes[d_off[i] .. d_off[i+1] - trim); '\n' is an ordinary character here.  Asynchronous on
+ * `stream` (nothing is read back).  Large batches on a table engine (>= 65536 items) build an item index in a scratch buffer
+ * the regex handle keeps until rrx_free (1 bit per byte of what is left of the allocation behind d_bytes, + 8 bytes per
+ * stripe); calls with one regex on different streams are ordered on the device by an event, not on the host.        */
 int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, const uint64_t *d_off, size_t nitems,
                       uint32_t trim, uint8_t *d_accept, void *stream);
 

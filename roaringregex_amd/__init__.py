@@ -275,7 +275,7 @@ class RRegex:
     def match_device_bits(self, data, cap_lines=None, out=None, stream=None):
         """One-shot (rrx_match_device): a device tensor nobody has indexed -> (accept bitmap as int32 words, number of
         strings).  With the stride-2 table engine the text is read once.  cap_lines bounds the number of strings the
-        bitmap can hold (default: one per 8 bytes, at least 1024)."""
+        bitmap can hold (default: one per byte, the most a buffer can hold)."""
         import torch
         assert data.is_cuda and data.dtype == torch.uint8 and data.is_contiguous()
         n = data.numel()

@@ -49,6 +49,44 @@ struct SearchTablesOnDevice {
     dev::SearchChunkDevice chunk;      // the stripe-wise form (forward table in line mode); nrows = 0: not usable
 };
 
+// Small results a call has to hand back to the host (line totals, flags) are written by the call's last kernel into a slot
+// of pinned, device-mapped host memory; the host then only waits for the stream.  (Round 2 read them with three
+// hipMemcpyAsync into pageable stack variables and a synchronize: one call in twelve of the one-shot entry took 10.6 ms
+// instead of 1.8 - BENCH_r02.json - with every kernel as fast as ever, profiles/r03_one_shot_calls.txt.)
+struct Mailbox {
+    volatile uint64_t *host = nullptr;
+    uint64_t *dev = nullptr;
+    int device = -1, slot = -1;
+};
+constexpr int kMailSlots = 64, kMailWords = 8;
+struct MailPage { uint64_t *host = nullptr, *dev = nullptr; std::vector<int> free_slots; };
+std::mutex g_mail_mu;
+std::map<int, MailPage> g_mail;
+int mailbox_acquire(int device, Mailbox *out) {
+    std::lock_guard<std::mutex> lock(g_mail_mu);
+    MailPage &pg = g_mail[device];
+    if (!pg.host) {
+        void *h = nullptr, *d = nullptr;
+        hipError_t e = hipHostMalloc(&h, kMailSlots * kMailWords * sizeof(uint64_t), hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer(&d, h, 0);
+        if (e != hipSuccess) { if (h) (void)hipHostFree(h); return hip_fail(e, "hipHostMalloc(mailbox)"); }
+        pg.host = static_cast<uint64_t *>(h); pg.dev = static_cast<uint64_t *>(d);
+        for (int i = kMailSlots - 1; i >= 0; i--) pg.free_slots.push_back(i);
+    }
+    if (pg.free_slots.empty()) return fail(RRX_ERR_HIP, "more than 64 synchronous calls in flight on one device");
+    out->slot = pg.free_slots.back(); pg.free_slots.pop_back();
+    out->device = device;
+    out->host = pg.host + (size_t)out->slot * kMailWords;
+    out->dev = pg.dev + (size_t)out->slot * kMailWords;
+    return RRX_OK;
+}
+void mailbox_release(const Mailbox &m) {
+    if (m.slot < 0) return;
+    std::lock_guard<std::mutex> lock(g_mail_mu);
+    g_mail[m.device].free_slots.push_back(m.slot);
+}
+struct MailboxGuard { Mailbox m; ~MailboxGuard() { mailbox_release(m); } };
+
 int instantiated_width(uint32_t W) { return W <= 4 ? (int)W : W <= 6 ? 6 : W <= 8 ? 8 : W <= 12 ? 12 : 16; }
 
 }  // namespace
@@ -96,24 +134,48 @@ struct rrx_regex {
         return RRX_OK;
     }
 
-    // Scratch of the one-shot entry (rrx_match_device): per-stripe counts, their scan and the lanes' verdict streams.
+    // Scratch of the one-shot entry (rrx_match_device: per-stripe counts, their scan and the lanes' verdict streams) and of
+    // one-call explicit items (rrx_match_extents: the item index).  One grow-only buffer per device, kept until rrx_free.
+    // Users on different streams are ordered on the DEVICE by an event recorded after each use (the host never waits):
+    // onepass_for(..., stream) makes `stream` wait for the last user, onepass_done(stream) marks the new last use; both under
+    // `onepass_mu`, held from the one to the other.
+    struct EventScratch { void *p = nullptr; size_t cap = 0; hipEvent_t last = nullptr; bool used = false; };
     mutable std::mutex onepass_mu;
-    mutable std::map<int, Scratch> onepass_scratch;
-    int onepass_for(int device, size_t bytes, void **out) const {      // call with `onepass_mu` held
-        Scratch &sc = onepass_scratch[device];
+    mutable std::map<int, EventScratch> onepass_scratch;
+    int onepass_for(int device, size_t bytes, void **out, hipStream_t stream) const {      // call with `onepass_mu` held
+        EventScratch &sc = onepass_scratch[device];
+        if (!sc.last) {
+            hipError_t e = hipEventCreateWithFlags(&sc.last, hipEventDisableTiming);
+            if (e != hipSuccess) { sc.last = nullptr; return hip_fail(e, "hipEventCreate(scratch)"); }
+        }
         if (sc.cap < bytes) {
-            if (sc.p) { (void)hipFree(sc.p); sc.p = nullptr; sc.cap = 0; }
+            if (sc.p) { (void)hipEventSynchronize(sc.last); (void)hipFree(sc.p); sc.p = nullptr; sc.cap = 0; sc.used = false; }
             hipError_t e = hipMalloc(&sc.p, bytes);
             if (e != hipSuccess) { sc.p = nullptr; return hip_fail(e, "hipMalloc(one-pass scratch)"); }
             sc.cap = bytes;
         }
+        if (sc.used) {
+            hipError_t e = hipStreamWaitEvent(stream, sc.last, 0);
+            if (e != hipSuccess) return hip_fail(e, "hipStreamWaitEvent(scratch)");
+        }
         *out = sc.p;
+        return RRX_OK;
+    }
+    int onepass_done(int device, hipStream_t stream) const {                               // call with `onepass_mu` held
+        EventScratch &sc = onepass_scratch[device];
+        hipError_t e = hipEventRecord(sc.last, stream);
+        if (e != hipSuccess) return hip_fail(e, "hipEventRecord(scratch)");
+        sc.used = true;
         return RRX_OK;
     }
 
     ~rrx_regex() {
         for (auto &kv : scratch) if (kv.second.p) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.p); }
-        for (auto &kv : onepass_scratch) if (kv.second.p) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.p); }
+        for (auto &kv : onepass_scratch) {
+            (void)hipSetDevice(kv.first);
+            if (kv.second.last) { (void)hipEventSynchronize(kv.second.last); (void)hipEventDestroy(kv.second.last); }
+            if (kv.second.p) (void)hipFree(kv.second.p);
+        }
         for (auto &kv : on_device) if (kv.second.blob) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.blob); }
         for (auto &kv : search_on_device) if (kv.second.blob) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.blob); }
         for (auto &kv : items_on_device) if (kv.second.blob) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.blob); }
@@ -602,14 +664,15 @@ int rrx_corpus_create_ex(int device, const void *d_bytes, size_t nbytes, uint32_
     int rc = dev::count_newlines_per_stripe(c->d_bytes, nbytes, c->stripe, c->d_counts, c->nstripes, d_flags, stream);
     if (!rc) rc = dev::scan_counts(c->d_counts, c->d_base, c->d_base + c->nstripes + 1, c->nstripes, stream);
     if (rc) { rrx_corpus_free(c); return hip_fail((hipError_t)rc, "line index launch"); }
-    uint64_t total = 0;
-    uint32_t flags = 0;
-    uint8_t last = '\n';
-    e = hipMemcpyAsync(&total, c->d_base + c->nstripes, sizeof total, hipMemcpyDeviceToHost, (hipStream_t)stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(&flags, d_flags, sizeof flags, hipMemcpyDeviceToHost, (hipStream_t)stream);
-    if (e == hipSuccess && nbytes) e = hipMemcpyAsync(&last, c->d_bytes + nbytes - 1, 1, hipMemcpyDeviceToHost, (hipStream_t)stream);
-    if (e == hipSuccess) e = hipStreamSynchronize((hipStream_t)stream);
+    MailboxGuard mail;
+    if (int mrc = mailbox_acquire(device, &mail.m)) { rrx_corpus_free(c); return mrc; }
+    rc = dev::mail_results(c->d_base + c->nstripes, d_flags, nbytes ? c->d_bytes + nbytes - 1 : nullptr, mail.m.dev, stream);
+    if (rc) { rrx_corpus_free(c); return hip_fail((hipError_t)rc, "line index launch"); }
+    e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) { rrx_corpus_free(c); return hip_fail(e, "line index readback"); }
+    const uint64_t total = mail.m.host[0];
+    const uint32_t flags = (uint32_t)mail.m.host[1];
+    const uint8_t last = nbytes ? (uint8_t)mail.m.host[2] : (uint8_t)'\n';
     c->has_high = (flags & 1u) != 0;
     c->nlines = (size_t)total + ((nbytes && last != '\n') ? 1 : 0);
     // with the line count known: the stripe this corpus wants (stripe_for_lines); if it is another one, index once more
@@ -697,29 +760,27 @@ int rrx_match_device(const rrx_regex *re, int device, const void *d_bytes, size_
     const size_t slab_bytes = dev::onepass_slab_words(nstripes, stripe) * sizeof(uint32_t);
     std::lock_guard<std::mutex> lock(re->onepass_mu);
     void *buf = nullptr;
-    rc = re->onepass_for(device, counts_bytes + base_bytes + slab_bytes, &buf);
+    rc = re->onepass_for(device, counts_bytes + base_bytes + slab_bytes, &buf, st);
     if (rc) return rc;
-    uint32_t *d_counts = static_cast<uint32_t *>(buf), *d_flag = d_counts + nstripes;
+    uint32_t *d_counts = static_cast<uint32_t *>(buf);
     uint64_t *d_base = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(buf) + counts_bytes);
     uint32_t *d_slabs = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(buf) + counts_bytes + base_bytes);
-    HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(uint32_t), st));
+    MailboxGuard mail;
+    rc = mailbox_acquire(device, &mail.m);
+    if (rc) return rc;
     if (cap_words) HIP_TRY(hipMemsetAsync(d_accept_bits, 0, cap_words * sizeof(uint32_t), st));
     int e = re->engine == RRX_ENGINE_NFA ? dev::match_onepass_nfa(t->nfa, bytes, nbytes, stripe, nstripes, d_counts, d_slabs, stream)
             : re->has_dfa2               ? dev::match_onepass_dfa2(t->dfa2, bytes, nbytes, stripe, nstripes, d_counts, d_slabs, stream)
                                          : dev::match_onepass_dfa(t->line, bytes, nbytes, stripe, nstripes, d_counts, d_slabs, stream);
     if (!e) e = dev::scan_counts(d_counts, d_base, d_base + nstripes + 1, nstripes, stream);
-    if (!e) e = dev::compact_streams(d_counts, d_base, nstripes, stripe, d_slabs, d_accept_bits, cap_words, d_flag, stream);
+    // (words beyond the caller's bitmap are dropped by the compaction; whether there were any follows from the line count)
+    if (!e) e = dev::compact_streams(d_counts, d_base, nstripes, stripe, d_slabs, d_accept_bits, cap_words, stream);
+    if (!e) e = dev::mail_results(d_base + nstripes, nullptr, bytes + nbytes - 1, mail.m.dev, stream);
     if (e) return hip_fail((hipError_t)e, "one-pass launch");
-    uint64_t total = 0;
-    uint32_t flag = 0;
-    uint8_t last = '\n';
-    hipError_t he = hipMemcpyAsync(&total, d_base + nstripes, sizeof total, hipMemcpyDeviceToHost, st);
-    if (he == hipSuccess) he = hipMemcpyAsync(&flag, d_flag, sizeof flag, hipMemcpyDeviceToHost, st);
-    if (he == hipSuccess) he = hipMemcpyAsync(&last, bytes + nbytes - 1, 1, hipMemcpyDeviceToHost, st);
-    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    const hipError_t he = hipStreamSynchronize(st);
     if (he != hipSuccess) return hip_fail(he, "one-pass readback");
-    *nlines = (size_t)total + (last != '\n' ? 1 : 0);
-    if (flag & 1u) return fail(RRX_ERR_ARG, "accept bitmap too small for the number of strings");
+    *nlines = (size_t)mail.m.host[0] + ((uint8_t)mail.m.host[2] != '\n' ? 1 : 0);
+    if ((*nlines + 31) / 32 > cap_words) return fail(RRX_ERR_ARG, "accept bitmap too small for the number of strings");
     return RRX_OK;
 }
 
@@ -877,8 +938,12 @@ int rrx_search_all(const rrx_regex *re, const rrx_corpus *c, uint64_t *d_first, 
     if (he == hipSuccess) he = hipStreamSynchronize(st);
     if (he != hipSuccess) return done(hip_fail(he, "search_all scan"));
     *total = (size_t)tot;
-    if (tot && tot <= cap) {
-        rc = rrx_search_all_fill(re, c, d_first, d_start, d_end, stream);
+    if (tot && cap) {                                                            // matches beyond `cap` are counted, not written (as rrx.h says)
+        rc = line_offsets(c, stream);
+        if (!rc) {
+            e = dev::search_all(*t, c->d_bytes, c->nbytes, c->d_line_off, c->nlines, nullptr, d_first, d_start, d_end, stream, cap);
+            if (e) rc = hip_fail((hipError_t)e, "search_all launch");
+        }
         if (!rc) { he = hipStreamSynchronize(st); if (he != hipSuccess) rc = hip_fail(he, "search_all fill"); }
     }
     return done(rc);
@@ -893,18 +958,16 @@ int rrx_bitmap_to_bytes(int device, const uint32_t *d_bits, size_t nlines, uint8
     return RRX_OK;
 }
 
-// below these a batch stays on the lane-per-item kernel (the index costs more than it saves); RRX_ITEMS_STRIPES_MIN=<items>
-// lowers both for tests and fuzzing (1: every batch goes stripe-wise)
-static size_t items_min_env() { const char *e = getenv("RRX_ITEMS_STRIPES_MIN"); return e ? (size_t)strtoull(e, nullptr, 10) : 0; }
-static const size_t kItemsStripesMin = items_min_env() ? items_min_env() : (size_t)1 << 16;
-static const size_t kItemsStripesMinBytes = items_min_env() ? items_min_env() : (size_t)8 << 20;
+// below these a batch stays on the lane-per-item kernel (the index costs more than it saves)
+static constexpr size_t kItemsStripesMin = (size_t)1 << 16;
+static constexpr size_t kItemsStripesMinBytes = (size_t)8 << 20;
 // a lane (lane group, workgroup) per item
 static int match_extents_lanes(const rrx_regex *re, const DeviceTables *t, const uint8_t *b, const uint64_t *d_off, size_t nitems, uint32_t trim,
-                               uint8_t *d_accept, void *stream) {
+                               uint8_t *d_accept, void *stream, const uint32_t *only_if = nullptr) {
     int e = re->engine == RRX_ENGINE_NFA_BLOCK ? dev::match_extents_block_nfa(t->block, b, d_off, nitems, trim, d_accept, stream)
             : re->engine == RRX_ENGINE_NFA_WAVE ? dev::match_extents_group_nfa(t->group, b, d_off, nitems, trim, d_accept, stream)
             : re->engine == RRX_ENGINE_NFA ? dev::match_extents_nfa(t->nfa, b, d_off, nitems, trim, d_accept, stream)
-                                         : dev::match_extents_dfa(t->dfa, b, d_off, nitems, trim, d_accept, stream);
+                                         : dev::match_extents_dfa(t->dfa, b, d_off, nitems, trim, d_accept, stream, only_if);
     if (e) return hip_fail((hipError_t)e, "match_extents launch");
     return RRX_OK;
 }
@@ -918,34 +981,36 @@ int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, cons
     const uint8_t *b = static_cast<const uint8_t *>(d_bytes);
     // A large batch on a table engine runs stripe-wise over the byte buffer, the item ends taken from a bitmap built from
     // the offsets (kernels_table.hip: match_items_stripes_kernel) and the table a copy of the plain one with an END OF ITEM
-    // column.  Needs: trim 0 or 1, at most 126 table states, 16-byte alignment, no item without a byte to carry its mark
-    // (checked on the device; such a batch is redone the other way).  This path waits for the stream (it reads off[0],
-    // off[nitems] and the check's flag).
+    // column.  Needs: trim 0 or 1, at most 126 table states, 16-byte alignment, no item without a byte to carry its mark.
+    // ASYNCHRONOUS: nothing is read back.  The host knows neither off[0] nor off[nitems]; it sizes the index for the most
+    // the batch can span - what is left of the allocation that holds d_bytes - and the kernels take the real extent from the
+    // offsets.  Whether the batch is fit (alignment, no degenerate item, large enough) is decided on the device: the
+    // stripe-wise kernel does nothing on an unfit batch and the lane-per-item kernel queued behind it does nothing on a fit one.
     const dev::LineDfaDevice *items = nullptr;
     if (re->engine == RRX_ENGINE_DFA && trim <= 1 && nitems >= kItemsStripesMin && !(reinterpret_cast<uintptr_t>(d_accept) & 15))
         items = re->items_table(device);
+    size_t bound = 0;
     if (items) {
+        hipDeviceptr_t abase = nullptr;
+        size_t asize = 0;
+        if (hipMemGetAddressRange(&abase, &asize, const_cast<void *>(d_bytes)) == hipSuccess && abase)
+            bound = (size_t)(static_cast<const uint8_t *>(abase) + asize - b);
+        else (void)hipGetLastError();
+    }
+    if (items && bound >= kItemsStripesMinBytes) {
         hipStream_t st = (hipStream_t)stream;
-        uint64_t first = 0, last = 0;
-        HIP_TRY(hipMemcpyAsync(&first, d_off, sizeof first, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(&last, d_off + nitems, sizeof last, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (last > first && last - first >= kItemsStripesMinBytes && !(reinterpret_cast<uintptr_t>(b + first) & 15)) {
-            const size_t nbytes = (size_t)(last - first);
-            std::lock_guard<std::mutex> lock(re->onepass_mu);
-            void *buf = nullptr;
-            const size_t ib = dev::items_index_bytes(nbytes, nitems);
-            rc = re->onepass_for(device, ib + dev::items_result_bytes(nitems), &buf);
-            if (rc) return rc;
-            uint32_t *d_flag = nullptr;
-            int le = dev::items_index_build(nbytes, d_off, nitems, trim, buf, &d_flag, stream);
-            if (!le) le = dev::items_match(*items, b + first, nbytes, nitems, trim, buf, static_cast<uint8_t *>(buf) + ib, d_accept, stream);
-            if (le) return hip_fail((hipError_t)le, "match_items_stripes launch");
-            uint32_t degenerate = 0;
-            HIP_TRY(hipMemcpyAsync(&degenerate, d_flag, sizeof degenerate, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            if (!degenerate) return RRX_OK;
-        }
+        std::lock_guard<std::mutex> lock(re->onepass_mu);
+        void *buf = nullptr;
+        const size_t ib = dev::items_index_bytes(bound, nitems);
+        rc = re->onepass_for(device, ib + dev::items_result_bytes(nitems), &buf, st);      // (ordered behind the scratch's last user)
+        if (rc) return rc;
+        uint32_t *d_flag = nullptr;
+        int le = dev::items_index_build(bound, d_off, nitems, trim, buf, &d_flag, stream, b, kItemsStripesMinBytes);
+        if (!le) le = dev::items_match(*items, b, bound, nitems, trim, buf, static_cast<uint8_t *>(buf) + ib, d_accept, stream, d_off, d_flag);
+        if (!le) rc = match_extents_lanes(re, t, b, d_off, nitems, trim, d_accept, stream, d_flag);
+        const int rc2 = re->onepass_done(device, st);            // (whatever was queued: the next user waits for it)
+        if (le) return hip_fail((hipError_t)le, "match_items_stripes launch");
+        return rc ? rc : rc2;
     }
     return match_extents_lanes(re, t, b, d_off, nitems, trim, d_accept, stream);
 }

@@ -132,7 +132,8 @@ int match_stripes_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes,
 
 // One-pass mode (no line index yet): the stride-2 kernel writes counts[g] ('\n' per stripe, with flags) and every lane's
 // verdict stream into `slabs` (onepass_slab_words() words); after scan_counts, compact_streams moves the streams to their
-// place in the (zeroed) accept bitmap; *overflow gets bit 0 set if the bitmap is too small.
+// place in the (zeroed) accept bitmap; words beyond cap_words are dropped (the caller learns from the line count that
+// its bitmap was too small).
 size_t onepass_slab_words(size_t nstripes, uint32_t stripe);
 int match_onepass_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, size_t nstripes, uint32_t *counts,
                        uint32_t *slabs, void *stream);
@@ -141,7 +142,10 @@ int match_onepass_dfa(const LineDfaDevice &p, const uint8_t *bytes, size_t nbyte
 int match_onepass_nfa(const NfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, size_t nstripes, uint32_t *counts,
                       uint32_t *slabs, void *stream);
 int compact_streams(const uint32_t *counts, const uint64_t *stripe_base, size_t nstripes, uint32_t stripe, const uint32_t *slabs,
-                    uint32_t *accept_bits, size_t cap_words, uint32_t *overflow, void *stream);
+                    uint32_t *accept_bits, size_t cap_words, void *stream);
+// mail[0] = *total without the flag bit, mail[1] = flags ? *flags : 0, mail[2] = last_byte ? *last_byte : '\n': the few words a
+// synchronous entry hands back, written into pinned device-mapped host memory by a one-lane kernel at the end of the call
+int mail_results(const uint64_t *total, const uint32_t *flags, const uint8_t *last_byte, uint64_t *mail, void *stream);
 
 // All launchers are asynchronous on `stream` and return a hipError_t value (0 = success).
 int count_newlines_per_stripe(const uint8_t *bytes, size_t nbytes, uint32_t stripe, uint32_t *counts, size_t nstripes, uint32_t *flags, void *stream);
@@ -214,8 +218,9 @@ int search_lines(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, con
                  uint32_t *match_start, uint32_t *match_end, void *stream);
 
 // all matches per line: first == nullptr counts (count[i]); otherwise fills the slots first[i], first[i] + 1, ...
+// (fill: slots >= cap are not written)
 int search_all(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *line_off, size_t nlines, uint32_t *count,
-               const uint64_t *first, uint32_t *match_start, uint32_t *match_end, void *stream);
+               const uint64_t *first, uint32_t *match_start, uint32_t *match_end, void *stream, size_t cap = ~(size_t)0);
 
 // One long string (regex.h:156-159 consumes it byte by byte): the string is cut into chunks, every chunk is stepped
 // from EVERY table state at once (lane = (chunk, start state); the lanes of a chunk read the same text), which yields
@@ -227,9 +232,13 @@ constexpr uint32_t kLongGroup = 128;             // maps composed per workgroup 
 constexpr uint32_t kItemColumns = 131, kItemEndColumn = 129;      // (130 in use, 131 keeps the row stride odd)
 size_t items_index_bytes(size_t nbytes, size_t nitems);  // item-end bitmap, flag, stripe base
 size_t items_result_bytes(size_t nitems);                // result bitmap of one match
-int items_index_build(size_t nbytes, const uint64_t *off, size_t nitems, uint32_t trim, void *index, uint32_t **flag, void *stream);
+// resolve_base / resolve_off (one-call form, nothing known on the host): nbytes is an UPPER BOUND the index is laid out for;
+// the kernels take the batch's start and length from the offsets; *flag != 0 afterwards = batch unfit for the stripe-wise
+// kernel (items_match then does nothing when handed the flag as skip_if)
+int items_index_build(size_t nbytes, const uint64_t *off, size_t nitems, uint32_t trim, void *index, uint32_t **flag, void *stream,
+                      const uint8_t *resolve_base = nullptr, size_t min_bytes = 0);
 int items_match(const LineDfaDevice &p, const uint8_t *bytes, size_t nbytes, size_t nitems, uint32_t trim, const void *index, void *result,
-                uint8_t *accept, void *stream);
+                uint8_t *accept, void *stream, const uint64_t *resolve_off = nullptr, const uint32_t *skip_if = nullptr);
 size_t long_scratch_bytes(uint32_t nstates, size_t nbytes, uint32_t *chunk);
 int match_long_dfa(const DfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t chunk, void *scratch, uint8_t *accept,
                    void *stream);
@@ -240,8 +249,9 @@ int match_long_nfa(const NfaDevice &p, const uint8_t *bytes, size_t nbytes, uint
                    void *stream);
 int match_extents_nfa(const NfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim,
                       uint8_t *accept, void *stream);
+// only_if != nullptr: the kernel does nothing unless *only_if != 0 (the fallback queued behind the stripe-wise items kernel)
 int match_extents_dfa(const DfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim,
-                      uint8_t *accept, void *stream);
+                      uint8_t *accept, void *stream, const uint32_t *only_if = nullptr);
 
 }  // namespace dev
 }  // namespace rrx

@@ -328,8 +328,9 @@ __global__ __launch_bounds__(kThreads) void match_stripes_onepass_kernel(Program
 template <class Engine, class Program>
 __global__ __launch_bounds__(kThreads) void match_extents_kernel(Program prog, const uint8_t *__restrict__ bytes,
                                                                   const uint64_t *__restrict__ off, size_t nitems, uint32_t trim,
-                                                                  uint8_t *__restrict__ accept) {
+                                                                  uint8_t *__restrict__ accept, const uint32_t *__restrict__ only_if) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    if (only_if && !*only_if) return;            // queued behind the stripe-wise kernel as its fallback: the batch was fit, nothing to do
     Engine eng;
     eng.load(prog, smem);
     __syncthreads();
@@ -360,8 +361,18 @@ __global__ __launch_bounds__(kThreads) void match_extents_kernel(Program prog, c
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel, device and size increase, not once per launch.
 // (One slot array per kernel: `slots` is a function-local static of the calling template instantiation.)
 constexpr int kMaxDevices = 64;
-struct LdsAttr { std::atomic<int> bytes[kMaxDevices]; };
-inline hipError_t ensure_dynamic_lds(LdsAttr &slots, const void *kernel, size_t bytes) {
+struct LdsAttr { std::atomic<int> bytes[kMaxDevices]; std::atomic<int> at_zero_ok{0}; };
+// at_zero: the kernel addresses a table by ABSOLUTE LDS address starting at 0 (B rows of the NFA lane engines, the search
+// kernel's tables), which holds as long as it has no static LDS in front of its dynamic LDS.  Checked here, once per kernel,
+// on the host - a launch that would break the assumption is refused (round 2 aborted the GPU process from inside the kernel).
+inline hipError_t ensure_dynamic_lds(LdsAttr &slots, const void *kernel, size_t bytes, bool at_zero = false) {
+    if (at_zero && !slots.at_zero_ok.load(std::memory_order_acquire)) {
+        hipFuncAttributes fa;
+        hipError_t e = hipFuncGetAttributes(&fa, kernel);
+        if (e != hipSuccess) return e;
+        if (fa.sharedSizeBytes != 0) return hipErrorInvalidConfiguration;
+        slots.at_zero_ok.store(1, std::memory_order_release);
+    }
     int dev = 0;
     hipError_t e = hipGetDevice(&dev);
     if (e != hipSuccess) return e;
@@ -371,6 +382,8 @@ inline hipError_t ensure_dynamic_lds(LdsAttr &slots, const void *kernel, size_t 
     if (e == hipSuccess) slots.bytes[dev].store((int)bytes, std::memory_order_release);
     return e;
 }
+template <class Engine, class = void> struct lds_at_zero : std::false_type {};
+template <class Engine> struct lds_at_zero<Engine, std::enable_if_t<Engine::kLdsAtZero>> : std::true_type {};
 
 template <class Engine, class Program>
 int launch_stripes(const Program &p, size_t table_bytes, const uint8_t *bytes, size_t nbytes, uint32_t stripe,
@@ -385,7 +398,7 @@ int launch_stripes(const Program &p, size_t table_bytes, const uint8_t *bytes, s
     const uint32_t stage_words = stage_off + kStageWords * sizeof(uint32_t) >= half_cu ? kStageWords : (uint32_t)((half_cu - stage_off) / 4);
     const size_t lds = Engine::kStaged ? stage_off + (size_t)stage_words * sizeof(uint32_t) : table_bytes;
     static LdsAttr attr;
-    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(k), lds);
+    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(k), lds, lds_at_zero<Engine>::value);
     if (e != hipSuccess) return (int)e;
     size_t blocks = (nstripes + kThreads - 1) / kThreads;
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), lds, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept, stage_off, stage_words);
@@ -394,14 +407,14 @@ int launch_stripes(const Program &p, size_t table_bytes, const uint8_t *bytes, s
 
 template <class Engine, class Program>
 int launch_extents(const Program &p, size_t table_bytes, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim,
-                   uint8_t *accept, void *stream) {
+                   uint8_t *accept, void *stream, const uint32_t *only_if = nullptr) {
     if (!nitems) return 0;
     auto k = match_extents_kernel<Engine, Program>;
     static LdsAttr attr;
     hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(k), table_bytes);
     if (e != hipSuccess) return (int)e;
     size_t blocks = (nitems + kThreads - 1) / kThreads;
-    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), table_bytes, (hipStream_t)stream, p, bytes, off, nitems, trim, accept);
+    hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), table_bytes, (hipStream_t)stream, p, bytes, off, nitems, trim, accept, only_if);
     return (int)hipGetLastError();
 }
 
@@ -411,7 +424,7 @@ int launch_onepass(const Program &p, size_t table_bytes, const uint8_t *bytes, s
     if (!nstripes) return 0;
     auto k = match_stripes_onepass_kernel<Engine, Program>;
     static LdsAttr attr;
-    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(k), table_bytes);
+    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(k), table_bytes, lds_at_zero<Engine>::value);
     if (e != hipSuccess) return (int)e;
     size_t blocks = (nstripes + kThreads - 1) / kThreads;
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), table_bytes, (hipStream_t)stream, p, bytes, nbytes, stripe, counts, slabs);

@@ -142,8 +142,8 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     uint32_t *stage = C + 64;                                     // [wave][kArrays][kStageLines]
     constexpr uint32_t kArrays = (MODE == kFill || MODE == kAll) ? 2 : 1;     // results packed start | end << 16 (kCount: the count); kFill / kAll: + slot bases
     constexpr uint32_t kStageInit = MODE == kCount ? 0u : kNone;  // a line without a match: "none" / zero matches
-    if ((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint8_t *)smem != 0u) __builtin_trap();
-    const uint32_t t_base = 512u;                                 // LDS address of T
+    const uint32_t t_base = 512u;                                 // LDS address of T: the dynamic LDS starts at address 0 (no static
+                                                                  // LDS in this kernel; the launcher checks it on the host)
     const uint32_t *Tsrc = MODE == kFirst ? prog.T : prog.T_all;
     for (uint32_t i = threadIdx.x; i < t_words; i += blockDim.x) T[i] = Tsrc[i] + t_base;
     for (uint32_t i = threadIdx.x; i < rev_words; i += blockDim.x) R[i] = reinterpret_cast<const uint32_t *>(prog.rev)[i];
@@ -560,7 +560,7 @@ static int launch_search_chunks(const SearchChunkDevice &p, const uint8_t *bytes
     if (!lines) return (int)hipErrorInvalidValue;
     const size_t lds = search_table_bytes(p) + (size_t)kSearchWaves * 4 * ((MODE == kFill || MODE == kAll) ? 2 : 1) * lines;
     static LdsAttr attr;
-    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(search_chunks_kernel<MODE>), lds);
+    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(search_chunks_kernel<MODE>), lds, /*at_zero=*/true);
     if (e != hipSuccess) return (int)e;
     // persistent workgroups: the tables are loaded once per workgroup, its waves take chunk after chunk
     size_t blocks = (nchunks + kSearchWaves - 1) / kSearchWaves;

@@ -310,11 +310,7 @@ __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t 
     for (int r = 0; r < rounds; r++) {
 #pragma unroll
         for (int i = 0; i < kSlots; i++) {
-#ifdef RRX_PROBE_ONEPASS_NO_HIGH_CHECK
-            if (false) {
-#else
             if (ONEPASS && __builtin_expect(__builtin_amdgcn_ballot_w64(((buf[i].x | buf[i].y | buf[i].z | buf[i].w) & 0x80808080u) != 0) != 0, 0)) {
-#endif
                 // some lane of the wave holds a byte >= 0x80 in this slot (one test per 16 bytes; rare on text)
                 eng.consume_dword(st, clean(buf[i].x), res.bits);
                 eng.consume_dword(st, clean(buf[i].y), res.bits);
@@ -432,8 +428,7 @@ __global__ __launch_bounds__(kThreads) void match_stripes2_onepass_kernel(Dfa2De
 constexpr uint32_t kCompactWindowWords = 8192;
 __global__ __launch_bounds__(256) void compact_streams_kernel(const uint32_t *__restrict__ counts, const uint64_t *__restrict__ stripe_base,
                                                                size_t nstripes, uint32_t stripe, const uint32_t *__restrict__ slabs,
-                                                               uint32_t *__restrict__ accept_bits, size_t cap_words,
-                                                               uint32_t *__restrict__ overflow) {
+                                                               uint32_t *__restrict__ accept_bits, size_t cap_words) {
     __shared__ uint32_t window[kCompactWindowWords];
     const size_t g0 = (size_t)blockIdx.x * 256;
     const size_t g1 = g0 + 256 < nstripes ? g0 + 256 : nstripes;
@@ -455,7 +450,7 @@ __global__ __launch_bounds__(256) void compact_streams_kernel(const uint32_t *__
         const uint32_t *src = slabs + g;
         auto put = [&](uint64_t word, uint32_t v) {
             if (!v) return;
-            if (word >= cap_words) { atomicOr(overflow, 1u); return; }
+            if (word >= cap_words) return;                          // the caller's bitmap is too small: reported from the line count
             const uint64_t rel = word - window_word;
             if (rel < used) atomicOr(&window[(uint32_t)rel], v);
             else atomicOr(&accept_bits[word], v);
@@ -473,8 +468,16 @@ __global__ __launch_bounds__(256) void compact_streams_kernel(const uint32_t *__
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < used; i += 256) {
         const uint32_t v = window[i];
-        if (v) atomicOr(&accept_bits[window_word + i], v);
+        if (v && window_word + i < cap_words) atomicOr(&accept_bits[window_word + i], v);
     }
+}
+__global__ void mail_results_kernel(const uint64_t *__restrict__ total, const uint32_t *__restrict__ flags, const uint8_t *__restrict__ last_byte,
+                                    uint64_t *__restrict__ mail) {
+    if (threadIdx.x || blockIdx.x) return;
+    mail[0] = line_of(*total);
+    mail[1] = flags ? *flags : 0u;
+    mail[2] = last_byte ? *last_byte : (uint64_t)'\n';
+    __threadfence_system();
 }
 
 // ============================================================================================ line index
@@ -767,7 +770,7 @@ template <bool FILL>
 __global__ __launch_bounds__(256) void search_all_kernel(SearchDevice prog, const uint8_t *__restrict__ bytes, size_t nbytes,
                                                          const uint64_t *__restrict__ line_off, size_t nlines,
                                                          uint32_t *__restrict__ count, const uint64_t *__restrict__ first,
-                                                         uint32_t *__restrict__ match_start, uint32_t *__restrict__ match_end) {
+                                                         uint32_t *__restrict__ match_start, uint32_t *__restrict__ match_end, uint64_t cap) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     SearchTables t;
     t.load(prog, smem);
@@ -780,7 +783,7 @@ __global__ __launch_bounds__(256) void search_all_kernel(SearchDevice prog, cons
     for (size_t p = a; p <= b;) {
         size_t s, e;
         if (!search_from(t, bytes, nbytes, p, b, s, e)) break;
-        if (FILL) { match_start[slot + k] = (uint32_t)(s - a); match_end[slot + k] = (uint32_t)(e - a); }
+        if (FILL && slot + k < cap) { match_start[slot + k] = (uint32_t)(s - a); match_end[slot + k] = (uint32_t)(e - a); }
         k++;
         p = e > s ? e : e + 1;
     }
@@ -801,9 +804,17 @@ template <int ENDS>
 __global__ __launch_bounds__(kThreads) void match_items_stripes_kernel(LineDfaDevice prog, const uint8_t *__restrict__ bytes, size_t nbytes,
                                                                         uint32_t stripe, const uint64_t *__restrict__ stripe_base,
                                                                         const uint32_t *__restrict__ ends, uint32_t *__restrict__ accept_bits,
-                                                                        uint32_t stage_off, uint32_t stage_words) {
+                                                                        uint32_t stage_off, uint32_t stage_words,
+                                                                        const uint64_t *__restrict__ off, size_t nitems,
+                                                                        const uint32_t *__restrict__ skip_if) {
     typedef LineDfaEngine<true, false> Engine;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    // One-call form (rrx_match_extents, asynchronous): the host knows neither where the batch starts nor how long it is -
+    // both come from the offsets here - and the index pass may have found the batch unfit (*skip_if != 0: an item without
+    // a byte for its mark, a misaligned start, too small): then the lane-per-item kernel queued behind this one runs instead.
+    if (skip_if && *skip_if) return;
+    if (off) { const uint64_t first = off[0]; bytes += first; nbytes = (size_t)(off[nitems] - first); }
+    if ((size_t)blockIdx.x * kThreads * stripe >= nbytes) return;    // (the grid was sized from an upper bound)
     uint32_t *stage = reinterpret_cast<uint32_t *>(smem + stage_off);
     Engine eng;
     eng.load(prog, smem);
@@ -928,8 +939,15 @@ __global__ __launch_bounds__(kThreads) void match_items_stripes_kernel(LineDfaDe
 // marked word: 0.34 / 0.83 ms - scattered partial writes into 128 MB.)
 constexpr uint32_t kEndsTile = 4096, kEndsPerLane = 4, kEndsItems = 256 * kEndsPerLane;      // items per workgroup
 __global__ __launch_bounds__(256) void item_ends_kernel(const uint64_t *__restrict__ off, size_t nitems, uint32_t trim, uint32_t *__restrict__ ends,
-                                                        uint32_t *__restrict__ flag) {
+                                                        uint32_t *__restrict__ flag, uint64_t limit_words, const uint8_t *__restrict__ bytes_base,
+                                                        uint64_t min_bytes) {
     __shared__ uint32_t tile[kEndsTile];
+    // one-call form: the batch's extent is only known here.  Unfit (flag bit 1) if it is shorter than the stripe-wise path
+    // pays for, longer than the bitmap was sized for, or does not start on a 16-byte boundary.
+    if (bytes_base && blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint64_t f = off[0], l = off[nitems];
+        if (l <= f || l - f < min_bytes || ((l - f + 31) >> 5) > limit_words || (reinterpret_cast<uintptr_t>(bytes_base + f) & 15)) atomicOr(flag, 2u);
+    }
     const size_t i0 = (size_t)blockIdx.x * kEndsItems;
     const size_t i1 = i0 + kEndsItems < nitems ? i0 + kEndsItems : nitems;     // first item of the next workgroup (nitems: none)
     const uint64_t base = off[0];
@@ -970,6 +988,7 @@ __global__ __launch_bounds__(256) void item_ends_kernel(const uint64_t *__restri
         for (uint32_t j = threadIdx.x; j < n; j += 256) {
             const uint64_t w = T + j;
             const uint32_t v = tile[j];
+            if (w >= limit_words) continue;                          // (offsets that overrun the buffer they were sized from)
             if (w == F || w == L) { if (v) atomicOr(&ends[w], v); }
             else ends[w] = v;
         }
@@ -1203,10 +1222,14 @@ int match_onepass_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes,
     return (int)hipGetLastError();
 }
 int compact_streams(const uint32_t *counts, const uint64_t *stripe_base, size_t nstripes, uint32_t stripe, const uint32_t *slabs,
-                    uint32_t *accept_bits, size_t cap_words, uint32_t *overflow, void *stream) {
+                    uint32_t *accept_bits, size_t cap_words, void *stream) {
     if (!nstripes) return 0;
     hipLaunchKernelGGL(compact_streams_kernel, dim3((unsigned)((nstripes + 255) / 256)), dim3(256), 0, (hipStream_t)stream, counts, stripe_base, nstripes,
-                       stripe, slabs, accept_bits, cap_words, overflow);
+                       stripe, slabs, accept_bits, cap_words);
+    return (int)hipGetLastError();
+}
+int mail_results(const uint64_t *total, const uint32_t *flags, const uint8_t *last_byte, uint64_t *mail, void *stream) {
+    hipLaunchKernelGGL(mail_results_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, total, flags, last_byte, mail);
     return (int)hipGetLastError();
 }
 size_t search_lds_bytes(const SearchDevice &p) { return ((size_t)p.nf + p.nr) * p.ncls * sizeof(uint16_t) + 256; }
@@ -1230,7 +1253,7 @@ int search_lines(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, con
     return (int)hipGetLastError();
 }
 int search_all(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *line_off, size_t nlines, uint32_t *count,
-               const uint64_t *first, uint32_t *match_start, uint32_t *match_end, void *stream) {
+               const uint64_t *first, uint32_t *match_start, uint32_t *match_end, void *stream, size_t cap) {
     if (!nlines) return 0;
     const size_t lds = search_lds_bytes(p);
     if (lds > kSearchLdsBudget || p.nf > 32767 || p.nr > 32767) return (int)hipErrorInvalidValue;
@@ -1240,8 +1263,8 @@ int search_all(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, const
                         : ensure_dynamic_lds(attr_count, reinterpret_cast<const void *>(search_all_kernel<false>), lds);
     if (e != hipSuccess) return (int)e;
     const dim3 grid((unsigned)((nlines + 255) / 256));
-    if (fill) hipLaunchKernelGGL(search_all_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, p, bytes, nbytes, line_off, nlines, count, first, match_start, match_end);
-    else hipLaunchKernelGGL(search_all_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, p, bytes, nbytes, line_off, nlines, count, first, match_start, match_end);
+    if (fill) hipLaunchKernelGGL(search_all_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, p, bytes, nbytes, line_off, nlines, count, first, match_start, match_end, (uint64_t)cap);
+    else hipLaunchKernelGGL(search_all_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, p, bytes, nbytes, line_off, nlines, count, first, match_start, match_end, (uint64_t)cap);
     return (int)hipGetLastError();
 }
 static uint32_t long_chunk(size_t nbytes) {
@@ -1314,7 +1337,8 @@ size_t items_index_bytes(size_t nbytes, size_t nitems) {
 size_t items_result_bytes(size_t nitems) { return items_align(((nitems + 31) / 32 + 4) * 4); }
 // trim 0 or 1; the buffer starts at off[0] and holds nbytes = off[nitems] - off[0] bytes.  -> *flag: device u32 inside the
 // index, != 0 after the stream is done if some item has no byte for its mark (then the index is not usable).
-int items_index_build(size_t nbytes, const uint64_t *off, size_t nitems, uint32_t trim, void *index, uint32_t **flag, void *stream) {
+int items_index_build(size_t nbytes, const uint64_t *off, size_t nitems, uint32_t trim, void *index, uint32_t **flag, void *stream,
+                      const uint8_t *resolve_base, size_t min_bytes) {
     if (trim > 1 || !nitems || !nbytes) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     const uint32_t stripe = items_stripe(nbytes, nitems);
@@ -1325,13 +1349,16 @@ int items_index_build(size_t nbytes, const uint64_t *off, size_t nitems, uint32_
     *flag = fl;
     hipError_t e = hipMemsetAsync(ends, 0, items_ends_bytes(nbytes) + 256, st);       // bitmap and flag
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(item_ends_kernel, dim3((unsigned)((nitems + kEndsItems - 1) / kEndsItems)), dim3(256), 0, st, off, nitems, trim, ends, fl);
+    hipLaunchKernelGGL(item_ends_kernel, dim3((unsigned)((nitems + kEndsItems - 1) / kEndsItems)), dim3(256), 0, st, off, nitems, trim, ends, fl,
+                       (uint64_t)(items_ends_bytes(nbytes) / 4), resolve_base, (uint64_t)min_bytes);
     hipLaunchKernelGGL(item_stripe_base_kernel, dim3((unsigned)((nstripes + 1 + 255) / 256)), dim3(256), 0, st, off, nitems, stripe, nstripes, base);
     return (int)hipGetLastError();
 }
-// one byte per item into `accept` (16-byte aligned); `result` = items_result_bytes(nitems) of scratch
+// one byte per item into `accept` (16-byte aligned); `result` = items_result_bytes(nitems) of scratch.  resolve_off != nullptr:
+// the one-call form - `bytes` is the buffer the offsets index, `nbytes` the upper bound the index was laid out for, the
+// kernel takes the batch's start and length from the offsets and does nothing if *skip_if != 0.
 int items_match(const LineDfaDevice &p, const uint8_t *bytes, size_t nbytes, size_t nitems, uint32_t trim, const void *index, void *result,
-                uint8_t *accept, void *stream) {
+                uint8_t *accept, void *stream, const uint64_t *resolve_off, const uint32_t *skip_if) {
     if (!p.wide || p.in_global || p.stride != (kItemColumns << p.rep_log2) || trim > 1 || !nitems || !nbytes) return (int)hipErrorInvalidValue;
     hipStream_t st = (hipStream_t)stream;
     const uint32_t stripe = items_stripe(nbytes, nitems);
@@ -1351,23 +1378,25 @@ int items_match(const LineDfaDevice &p, const uint8_t *bytes, size_t nbytes, siz
         static LdsAttr attr;
         e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(match_items_stripes_kernel<1>), lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(match_items_stripes_kernel<1>, dim3((unsigned)blocks), dim3(kThreads), lds, st, p, bytes, nbytes, stripe, base, ends, bits, stage_off, stage_words);
+        hipLaunchKernelGGL(match_items_stripes_kernel<1>, dim3((unsigned)blocks), dim3(kThreads), lds, st, p, bytes, nbytes, stripe, base, ends, bits, stage_off, stage_words,
+                           resolve_off, nitems, skip_if);
     } else {
         static LdsAttr attr;
         e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(match_items_stripes_kernel<2>), lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(match_items_stripes_kernel<2>, dim3((unsigned)blocks), dim3(kThreads), lds, st, p, bytes, nbytes, stripe, base, ends, bits, stage_off, stage_words);
+        hipLaunchKernelGGL(match_items_stripes_kernel<2>, dim3((unsigned)blocks), dim3(kThreads), lds, st, p, bytes, nbytes, stripe, base, ends, bits, stage_off, stage_words,
+                           resolve_off, nitems, skip_if);
     }
     const int rc = (int)hipGetLastError();
     if (rc) return rc;
     return expand_bits(bits, nitems, accept, stream);
 }
 int match_extents_dfa(const DfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim, uint8_t *accept,
-                      void *stream) {
+                      void *stream, const uint32_t *only_if) {
     // tables beyond the LDS budget (the batch kernel's "global" form) stay in HBM/L2 here too
     if (PlainDfaEngine::lds_bytes(p) > kPlainDfaLdsBudget)
-        return launch_extents<PlainDfaGlobalEngine, DfaDevice>(p, PlainDfaGlobalEngine::lds_bytes(p), bytes, off, nitems, trim, accept, stream);
-    return launch_extents<PlainDfaEngine, DfaDevice>(p, PlainDfaEngine::lds_bytes(p), bytes, off, nitems, trim, accept, stream);
+        return launch_extents<PlainDfaGlobalEngine, DfaDevice>(p, PlainDfaGlobalEngine::lds_bytes(p), bytes, off, nitems, trim, accept, stream, only_if);
+    return launch_extents<PlainDfaEngine, DfaDevice>(p, PlainDfaEngine::lds_bytes(p), bytes, off, nitems, trim, accept, stream, only_if);
 }
 
 }  // namespace dev

@@ -7,8 +7,15 @@ import random
 import pytest
 from pyoracle import lib, ref_bitset_lib
 
-REF = ref_bitset_lib()
-pytestmark = pytest.mark.skipif(REF is None, reason="oracle/_ref not built (reference tree absent)")
+
+
+def _ref():
+    """Loaded inside the test, not at collection: a `-m gpu` run collects this module too, and the compiled reference TU
+    must not be mapped into a process that never uses it (VERDICT r2 #12)."""
+    ref = ref_bitset_lib()
+    if ref is None:
+        pytest.skip("oracle/_ref not built (reference tree absent)")
+    return ref
 
 
 def _arr(W, words):
@@ -33,6 +40,7 @@ def _rand_words(rng, W):
 @pytest.mark.parametrize("W", [1, 2, 4])
 def test_set_primitives_match_reference_bitset(W):
     O = lib()
+    REF = _ref()
     rng = random.Random(1000 + W)
     for f in ("ref_bs_cardinality", "ref_bs_and_cardinality", "ref_bs_iterate"):
         getattr(REF, f).restype = C.c_uint32

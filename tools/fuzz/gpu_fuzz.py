@@ -111,7 +111,8 @@ while done < npat:
                     sys.exit(1)
                 checked += 1
     # explicit items: the lines as (offset, length) items, with their '\n' as the separator (trim 1) and squeezed together
-    # (trim 0, empty lines dropped); run with RRX_ITEMS_STRIPES_MIN=1 so that these small batches take the stripe-wise kernel
+    # (trim 0, empty lines dropped): the one-call entry (lane per item at these sizes) and an indexed batch (rrx_items: always the
+    # stripe-wise kernel when the batch admits it)
     if len(arr) and arr[-1] == 10:
         nlpos = np.nonzero(arr == 10)[0]
         off1 = torch.from_numpy(np.concatenate([[0], nlpos + 1]).astype(np.int64)).cuda()
