@@ -246,10 +246,15 @@ struct Dfa2 {
 // produces a verdict for the fragment, which the compaction drops), counts its '\n' on the side, and keeps its verdict
 // stream in the workgroup's slab (LocalResults).  Bytes >= 0x80 cannot index the pair table: a text word that holds one is
 // rewritten with 0x00 in their place (which rejects the line just the same) under a wave-uniform branch.
-template <bool ONEPASS>
+// `phase` is an instrumentation hook: the shipping kernels pass NoPhaseHook (nothing is emitted); tools/probe/stamps builds
+// a kernel around this body whose hook writes a timestamp per workgroup and phase (where a launch's fixed cost goes).
+struct NoPhaseHook { __device__ __forceinline__ void operator()(int) const {} __device__ __forceinline__ void round(int) const {} };
+enum { kPhaseEntry = 0, kPhaseTablesLoaded, kPhaseFirstRound, kPhaseMainDone, kPhaseFollowDone, kPhaseWindowOut, kPhases };
+template <bool ONEPASS, class PhaseHook = NoPhaseHook>
 __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t *__restrict__ bytes, size_t nbytes, uint32_t stripe,
                                           const uint64_t *__restrict__ stripe_base, uint32_t *__restrict__ accept_bits,
-                                          uint32_t *__restrict__ counts, uint32_t *__restrict__ slabs) {
+                                          uint32_t *__restrict__ counts, uint32_t *__restrict__ slabs, PhaseHook phase = PhaseHook()) {
+    phase(kPhaseEntry);
     // T2 first: its entries hold 16-bit LDS addresses; the result window takes what T2 leaves of its region (16 KiB and
     // more for tables up to 30 KiB, 4 KiB at least).  The arrays are static, so P's base is a link-time constant.
     __shared__ __attribute__((aligned(16))) struct {
@@ -264,6 +269,7 @@ __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t 
     if (!ONEPASS)
         for (uint32_t i = threadIdx.x; i < stage_words; i += kThreads) stage[i] = 0;
     __syncthreads();
+    phase(kPhaseTablesLoaded);
 
     const size_t g0 = (size_t)blockIdx.x * kThreads;
     uint64_t window_word = 0;
@@ -308,6 +314,8 @@ __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t 
     uint32_t last_word = 0;                                       // the last text word of my stripe (whole rounds only)
     bool ahead = false;                                           // buf holds the 128 bytes behind my stripe
     for (int r = 0; r < rounds; r++) {
+        if (r == 1) phase(kPhaseFirstRound);
+        phase.round(r);
 #pragma unroll
         for (int i = 0; i < kSlots; i++) {
             if (ONEPASS && __builtin_expect(__builtin_amdgcn_ballot_w64(((buf[i].x | buf[i].y | buf[i].z | buf[i].w) & 0x80808080u) != 0) != 0, 0)) {
@@ -338,6 +346,7 @@ __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t 
         }
     }
     pos += (size_t)rounds * kRound;
+    phase(kPhaseMainDone);
     auto byte_at = [&](size_t q) -> uint32_t { const uint32_t b = bytes[q]; return (ONEPASS && b >= 0x80u) ? 0u : b; };
 
     // ---- tail of the corpus inside my stripe (only the last stripe has one): whole pairs, then an odd last byte.
@@ -396,6 +405,7 @@ __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t 
         followed = true;
     }
     res.finish();
+    phase(kPhaseFollowDone);
     if (ONEPASS)
         counts[g] = newlines | ((followed || closed_by_end_of_data) ? kExtraResult : 0u) | (last_byte == '\n' ? kEndsOnNewline : 0u);
     }
@@ -408,6 +418,7 @@ __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t 
             if (v) atomicOr(&accept_bits[window_word + i], v);
         }
     }
+    phase(kPhaseWindowOut);
 }
 __global__ __launch_bounds__(kThreads) void match_stripes2_kernel(Dfa2Device prog, const uint8_t *__restrict__ bytes, size_t nbytes,
                                                                    uint32_t stripe, const uint64_t *__restrict__ stripe_base,

@@ -1,7 +1,7 @@
 """From a rocprofv3 --kernel-trace CSV of bench.py: the kernels of every one-shot call (rrx_match_device), their durations
 and the device-side span of the call (first kernel start -> last kernel end), next to bench.py's own event time per call.
 Answers VERDICT r2 #6: was the 10.6 ms call a kernel or a host gap?   usage: one_shot_calls.py <dir with the csv> [bench json]"""
-import csv, glob, json, os, sys
+import csv, glob, json, os, re, sys
 d = sys.argv[1]
 rows = []
 for f in glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True):
@@ -14,7 +14,8 @@ for s, e, n in rows:
         cur = {"k": [], "start": s}
         calls.append(cur)
     if cur is not None:
-        short = n.split("(")[0].split("::")[-1][:44]
+        m = re.search(r"(\w+_kernel)", n)
+        short = m.group(1) if m else n[:40]
         cur["k"].append((short, (e - s) / 1e3))
         cur["end"] = e
         if "mail_results" in n:
