@@ -40,6 +40,7 @@ WORKLOADS = {
     # not a BASELINE config: the pattern class only an NFA engine can run (its subset construction has 2^41 sets)
     "nondet": ("ablines", "NONDET", 8 << 30, "extra: (a|b)*a(a|b){40} over lines of a/b (no DFA exists within memory)"),
     "nondet600": ("ablong", "NONDET600", 1 << 30, "extra: (a|b)*a(a|b){600} over lines of 500-900 a/b (604 positions, group-cooperative NFA)"),
+    "nondet5000": ("ablong", "NONDET5000", 1 << 28, "extra: (a|b)*a(a|b){5000} over lines of 500-900 a/b (5003 positions, wave-resident NFA)"),
 }
 
 
@@ -53,7 +54,7 @@ def patterns():
     u2 = [k["pattern"] for k in kat["kat"] if k["pattern"].startswith("(http|https|ftp)")][0]
     k1000 = kat["big_states"][-1]["pattern"]
     return {"U2": u2, "EMAIL": r"[A-Za-z0-9._]+@[A-Za-z0-9.]+", "A300": "a{1,300}", "K1000": k1000, "K1000C": ".*(" + k1000 + ").*",
-            "NONDET": "(a|b)*a(a|b){40}", "NONDET600": "(a|b)*a(a|b){600}"}
+            "NONDET": "(a|b)*a(a|b){40}", "NONDET600": "(a|b)*a(a|b){600}", "NONDET5000": "(a|b)*a(a|b){5000}"}
 
 
 def traffic_from_profile(workload, nbytes, engine_name):

@@ -34,7 +34,7 @@ struct DeviceTables {
     dev::LineDfaDevice line;     // line-mode form (batch kernel)
     dev::GroupNfaDevice group;   // group-cooperative NFA (16/32/64 lanes per string)
     dev::Dfa2Device dfa2;        // stride-2 line-mode table (corpora without bytes >= 0x80)
-    dev::BlockNfaDevice block;   // block-cooperative NFA (up to 65536 positions)
+    dev::WaveNfaDevice block;    // wave-resident NFA (up to 65536 positions)
 };
 
 // The plain table in the wide line-table format with one more column: 0..127 byte values ('\n' an ordinary byte), 128 =
@@ -99,7 +99,7 @@ struct rrx_regex {
     NfaProgram nfa;
     NfaProgram nfa_wave;         // up to 4096 positions, no carry groups (wave-cooperative engine)
     bool has_wave = false;
-    NfaProgram nfa_block;        // up to 65536 positions, exception edges in CSR form (block-cooperative engine)
+    NfaProgram nfa_block;        // up to 65536 positions, exception edges in CSR form (wave-resident engine)
     bool has_block = false;
     DfaProgram dfa;
     Dfa2Program dfa2;
@@ -309,28 +309,27 @@ struct rrx_regex {
         size_t oM = 0;
         size_t oCL = 0, oCP = 0, oXI = 0, oXO = 0, oXT = 0;
         if (engine == RRX_ENGINE_NFA_BLOCK) {
-            // block-cooperative form: T lanes x 64 positions, class rows like the group form, exception edges as CSR
+            // wave-resident form: 64 lanes x WL words, a B row per byte value (+ the line-mode '\n' row), exception edges as CSR
             const uint32_t W = nfa_block.W, N = nfa_block.nbits;
-            uint32_t T = 256;
-            while (T * 64 < N) T *= 2;
-            const uint32_t WP = 2 * T, K = trimmed.ncls + 1;
-            std::vector<uint32_t> M((size_t)3 * WP, 0), B((size_t)K * WP, 0);
+            const uint32_t WL = dev::wave_words_per_lane(W);
+            const uint32_t WP = 64 * WL;                                 // (word w of the set sits at flat index w: lane w / WL, index w % WL)
+            std::vector<uint32_t> M((size_t)3 * WP, 0), B((size_t)257 * WP, 0);
             const std::vector<uint32_t> *src[3] = {&nfa_block.fin, &nfa_block.self, &nfa_block.excm};
             for (int k = 0; k < 3; k++) for (uint32_t w = 0; w < W; w++) M[(size_t)k * WP + w] = (*src[k])[w];
-            for (uint32_t k = 1; k < trimmed.ncls; k++)
-                for (uint32_t w = 0; w < W; w++) B[(size_t)k * WP + w] = nfa_block.B[(size_t)trimmed.cls_rep[k] * W + w];
-            B[(size_t)(K - 1) * WP] = 1u;
-            uint8_t cl[256], cp[256];
-            for (int c = 0; c < 256; c++) cl[c] = cp[c] = trimmed.cls[c];
-            cl['\n'] = (uint8_t)(K - 1);
+            for (uint32_t c = 1; c < 128; c++)                            // 0x00 and >= 0x80: empty rows
+                for (uint32_t w = 0; w < W; w++) B[(size_t)c * WP + w] = nfa_block.B[(size_t)c * W + w];
+            B[(size_t)256 * WP] = 1u;                                     // '\n' in line mode: {position 0}
             std::vector<uint32_t> xt = nfa_block.xtgt;
             if (xt.empty()) xt.push_back(0);
             oM = put(M.data(), M.size() * 4);
             oB = put(B.data(), B.size() * 4);
-            oCL = put(cl, 256); oCP = put(cp, 256);
             oXO = put(nfa_block.xoff.data(), nfa_block.xoff.size() * 4);
             oXT = put(xt.data(), xt.size() * 4);
-            t.block.T = T; t.block.nbits = N; t.block.ncls = K; t.block.any_exc = nfa_block.n_exc ? 1 : 0;
+            t.block.WL = WL; t.block.nbits = N;
+            for (uint32_t w = 0; w < W; w++) {
+                if (nfa_block.self[w]) t.block.self_words |= 1u << (w % WL);
+                if (nfa_block.excm[w]) t.block.exc_words |= 1u << (w % WL);
+            }
         } else if (engine == RRX_ENGINE_NFA_WAVE) {
             // group-cooperative form: G lanes x 64 positions; B rows per byte CLASS (+ the line-mode '\n' row, last)
             const uint32_t W = nfa_wave.W, N = nfa_wave.nbits;
@@ -452,8 +451,7 @@ struct rrx_regex {
         const uint8_t *base = static_cast<const uint8_t *>(t.blob);
         if (engine == RRX_ENGINE_NFA_BLOCK) {
             t.block.masks = reinterpret_cast<const uint32_t *>(base + oM);
-            t.block.Bcls = reinterpret_cast<const uint32_t *>(base + oB);
-            t.block.cls_line = base + oCL; t.block.cls_plain = base + oCP;
+            t.block.Bbyte = reinterpret_cast<const uint32_t *>(base + oB);
             t.block.xoff = reinterpret_cast<const uint32_t *>(base + oXO);
             t.block.xtgt = reinterpret_cast<const uint32_t *>(base + oXT);
         } else if (engine == RRX_ENGINE_NFA_WAVE) {
@@ -537,7 +535,7 @@ int rrx_compile_ex(const char *pattern, int engine, rrx_regex **out) {
         // the wave-cooperative form: when asked for, or as the last resort of AUTO
         if (engine == RRX_ENGINE_NFA_WAVE || (engine == RRX_ENGINE_AUTO && !re->has_nfa && !re->has_dfa))
             re->has_wave = lower_nfa(red, dev::kGroupMaxBits, re->nfa_wave, /*allow_carry=*/false, /*gaps=*/true);
-        // the block-cooperative form (any automaton up to 65536 positions): when asked for, or when nothing else took it
+        // the wave-resident form (any automaton up to 65536 positions): when asked for, or when nothing else took it
         if (engine == RRX_ENGINE_NFA_BLOCK || (engine == RRX_ENGINE_AUTO && !re->has_nfa && !re->has_dfa && !re->has_wave))
             re->has_block = lower_nfa(red, dev::kBlockMaxBits, re->nfa_block, /*allow_carry=*/false, /*gaps=*/true);
     } catch (const PatternError &e) {
@@ -579,7 +577,7 @@ uint32_t rrx_ref_row(const rrx_regex *re, uint32_t state, unsigned c, uint32_t *
 int rrx_engine(const rrx_regex *re) { return re->engine; }
 const char *rrx_engine_name(const rrx_regex *re) {
     if (re->engine == RRX_ENGINE_NFA_WAVE) return "nfa-group-cooperative";
-    if (re->engine == RRX_ENGINE_NFA_BLOCK) return "nfa-block-cooperative";
+    if (re->engine == RRX_ENGINE_NFA_BLOCK) return "nfa-wave-resident";
     if (re->engine != RRX_ENGINE_DFA) return "nfa-shift-and";
     if (re->has_dfa2) return "dfa-stride2-table";      // (the byte-stride table still serves corpora with bytes >= 0x80)
     return re->line_global ? "dfa-global-table" : re->line_wide ? "dfa-wide-table" : "dfa-classed-table";
@@ -712,7 +710,7 @@ int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accep
     // the kernel merges words with atomic OR: start from an all-zero bitmap
     HIP_TRY(hipMemsetAsync(d_accept_bits, 0, rrx_corpus_bitmap_words(c) * sizeof(uint32_t), (hipStream_t)stream));
     int e = re->engine == RRX_ENGINE_NFA_BLOCK
-                ? dev::match_stripes_block_nfa(t->block, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream)
+                ? dev::match_stripes_wave_nfa(t->block, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream)
             : re->engine == RRX_ENGINE_NFA_WAVE
                 ? dev::match_stripes_group_nfa(t->group, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream)
             : re->engine == RRX_ENGINE_NFA
@@ -964,7 +962,7 @@ static constexpr size_t kItemsStripesMinBytes = (size_t)8 << 20;
 // a lane (lane group, workgroup) per item
 static int match_extents_lanes(const rrx_regex *re, const DeviceTables *t, const uint8_t *b, const uint64_t *d_off, size_t nitems, uint32_t trim,
                                uint8_t *d_accept, void *stream, const uint32_t *only_if = nullptr) {
-    int e = re->engine == RRX_ENGINE_NFA_BLOCK ? dev::match_extents_block_nfa(t->block, b, d_off, nitems, trim, d_accept, stream)
+    int e = re->engine == RRX_ENGINE_NFA_BLOCK ? dev::match_extents_wave_nfa(t->block, b, d_off, nitems, trim, d_accept, stream)
             : re->engine == RRX_ENGINE_NFA_WAVE ? dev::match_extents_group_nfa(t->group, b, d_off, nitems, trim, d_accept, stream)
             : re->engine == RRX_ENGINE_NFA ? dev::match_extents_nfa(t->nfa, b, d_off, nitems, trim, d_accept, stream)
                                          : dev::match_extents_dfa(t->dfa, b, d_off, nitems, trim, d_accept, stream, only_if);

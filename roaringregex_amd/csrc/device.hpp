@@ -69,17 +69,19 @@ struct GroupNfaDevice {
     const uint32_t *X = nullptr;                 // [n_exc][G][2]
 };
 
-// Block-cooperative NFA (automata beyond kGroupMaxBits positions): one WORKGROUP of T lanes holds one state set, 64
-// positions per lane (T = 256 ... 1024: up to 65536 positions); exception edges are CSR lists, not rows.
+// Wave-resident NFA (automata beyond kGroupMaxBits positions, kernels_wave.hip): ONE WAVE holds one state set, WL 32-bit
+// words per lane (WL = 1 ... 32: up to 65536 positions); exception edges are CSR lists, not rows.
 constexpr uint32_t kBlockMaxBits = 65536;
-struct BlockNfaDevice {
-    uint32_t T = 0, nbits = 0, ncls = 0, any_exc = 0;
-    const uint32_t *masks = nullptr;             // [3][T][2]: fin, self, excm
-    const uint32_t *Bcls = nullptr;              // [ncls][T][2], classes as in GroupNfaDevice
-    const uint8_t *cls_line = nullptr, *cls_plain = nullptr;
+struct WaveNfaDevice {
+    uint32_t WL = 0, nbits = 0;
+    uint32_t self_words = 0, exc_words = 0;     // bit i: word index i of some lane holds a self-loop / an exception position
+    const uint32_t *masks = nullptr;             // [3][64][WL]: fin, self, excm (word w of the set = lane w / WL, index w % WL)
+    const uint32_t *Bbyte = nullptr;             // [257][64][WL]: positions enterable on byte value 0..255 ('\n' an ordinary byte),
+                                                 //   row 256 = the line-mode '\n' row {position 0}
     const uint32_t *xoff = nullptr;              // [nbits + 1]
     const uint32_t *xtgt = nullptr;              // targets of position p: xtgt[xoff[p] .. xoff[p+1])
 };
+uint32_t wave_words_per_lane(uint32_t words);    // the instantiated WL that holds `words` 32-bit words (0: too many)
 
 // Plain DFA (extents kernel: '\n' is an ordinary byte).
 struct DfaDevice {
@@ -163,10 +165,10 @@ int match_stripes_group_nfa(const GroupNfaDevice &p, const uint8_t *bytes, size_
                             size_t nstripes, uint32_t *accept_bits, void *stream);
 int match_extents_group_nfa(const GroupNfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim,
                             uint8_t *accept, void *stream);
-int match_stripes_block_nfa(const BlockNfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
-                            size_t nstripes, uint32_t *accept_bits, void *stream);
-int match_extents_block_nfa(const BlockNfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim,
-                            uint8_t *accept, void *stream);
+int match_stripes_wave_nfa(const WaveNfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
+                           size_t nstripes, uint32_t *accept_bits, void *stream);
+int match_extents_wave_nfa(const WaveNfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim,
+                           uint8_t *accept, void *stream);
 
 // items i = bytes[off[i] .. off[i+1] - trim) ; trim = 1 drops a trailing delimiter byte per item
 // Search (the reference has acceptance only): two plain DFAs over the same byte classes.  fwd = "any bytes, then the

@@ -1,4 +1,5 @@
-// kernels_coop.hip — the cooperative NFA engines: a state set spread over a group of lanes or over a whole workgroup.
+// kernels_coop.hip — the group-cooperative NFA engine: a state set spread over a group of 16, 32 or 64 lanes (the wave-resident
+// engine for larger automata: kernels_wave.hip).
 // Shared device code: kernels_common.hpp.
 #include "kernels_common.hpp"
 
@@ -154,136 +155,6 @@ __global__ __launch_bounds__(256) void match_extents_group_kernel(GroupNfaDevice
     if (eng.lig == 0) accept[i] = ok ? 1 : 0;
 }
 
-// ============================================================================================ block-cooperative NFA
-// Automata beyond 4096 positions (the reference's Roaring class taken at its word, Parser.cpp:165: any size): one
-// WORKGROUP holds one state set, lane l the positions [64 l, 64 l + 64) - up to 1024 lanes = 65536 positions - and
-// steps one string.  What crosses waves goes through LDS, double-buffered so that a byte costs ONE barrier:
-//   * the shift: every lane publishes its upper word, the lane above picks it up after the barrier;
-//   * exception edges: kept SPARSE (CSR lists in HBM/L2; dense rows would take N*N/8 bytes), a lane walks the live
-//     exception positions of its 64 and ORs the target bits into an LDS accumulator, which the owning lanes merge and
-//     clear after the barrier - the set stays dense where it is populated, the rules that reach across it are lists;
-//   * the verdict is a barrier-with-OR, only on '\n' / end of string;
-//   * a wave = a block of 4096 positions; a block that is empty and receives nothing skips its row read and its step.
-// B rows are per byte class in HBM/L2, [class][lane] 8-byte words, read coalesced.  Control flow is workgroup-uniform
-// up to that per-wave skip.
-struct BlockNfa {
-    uint32_t fin0, fin1, self0, self1, exc0, exc1;
-    const uint2 *__restrict__ rows;        // HBM/L2 [ncls][T]
-    const uint8_t *cls;                    // LDS [256]
-    const uint32_t *__restrict__ xoff, *__restrict__ xtgt;
-    uint32_t *top, *texc;                  // LDS: [2][T], [2][2T]
-    bool any_exc;
-    uint32_t par = 0;
-    int lane, T;
-
-    static size_t lds_bytes(uint32_t T) { return (size_t)T * 4 * 6 + 256; }
-    __device__ void load(const BlockNfaDevice &p, uint8_t *lds, bool line_mode) {
-        lane = threadIdx.x; T = blockDim.x;
-        top = reinterpret_cast<uint32_t *>(lds);
-        texc = top + 2 * T;
-        uint8_t *c = reinterpret_cast<uint8_t *>(texc + 4 * T);
-        const uint8_t *src = line_mode ? p.cls_line : p.cls_plain;
-        for (int i = lane; i < 256; i += T) c[i] = src[i];
-        for (int i = lane; i < 4 * T; i += T) texc[i] = 0;
-        cls = c;
-        const uint2 *m = reinterpret_cast<const uint2 *>(p.masks);
-        uint2 v;
-        v = m[0 * T + lane]; fin0 = v.x; fin1 = v.y;
-        v = m[1 * T + lane]; self0 = v.x; self1 = v.y;
-        v = m[2 * T + lane]; exc0 = v.x; exc1 = v.y;
-        rows = reinterpret_cast<const uint2 *>(p.Bcls); xoff = p.xoff; xtgt = p.xtgt; any_exc = p.any_exc != 0;
-    }
-    // called by the whole workgroup (it is a barrier)
-    __device__ __forceinline__ bool accepting(uint32_t s0, uint32_t s1) const {
-        return __syncthreads_or((((s0 & fin0) | (s1 & fin1)) != 0) ? 1 : 0) != 0;
-    }
-    __device__ __forceinline__ void scatter(uint32_t e, uint32_t base, uint32_t *acc) const {
-        while (e) {
-            const uint32_t p = base + (uint32_t)__ffs(e) - 1u;
-            e &= e - 1;
-            for (uint32_t k = xoff[p], hi = xoff[p + 1]; k < hi; k++) { const uint32_t q = xtgt[k]; atomicOr(&acc[q >> 5], 1u << (q & 31)); }
-        }
-    }
-    // c is the same in every lane of the workgroup
-    template <bool LINE>
-    __device__ __forceinline__ void advance(uint32_t &s0, uint32_t &s1, uint32_t c) {
-        uint32_t *tp = top + par * T, *acc = texc + par * 2 * T;
-        tp[lane] = s1;
-        if (any_exc) { scatter(s0 & exc0, (uint32_t)lane * 64u, acc); scatter(s1 & exc1, (uint32_t)lane * 64u + 32u, acc); }
-        __syncthreads();
-        const uint32_t below = lane ? tp[lane - 1] : (LINE ? 0x80000000u : 0u);
-        uint32_t x0 = 0, x1 = 0;
-        if (any_exc) { x0 = acc[2 * lane]; x1 = acc[2 * lane + 1]; }
-        // A wave is a block of 4096 positions.  If none of them is live and nothing flows in - no bit from the lane
-        // below, no exception target - the block stays empty whatever the byte: the wave skips its B row (8 bytes per lane
-        // from HBM/L2) and the step.  Large automata with small live sets (a few of many alternatives alive) run mostly
-        // on this path; the set is dense only where it is populated.
-        if (__ballot((s0 | s1 | below | x0 | x1) != 0)) {
-            const uint2 b = rows[(size_t)cls[c] * T + lane];
-            uint32_t t0 = __builtin_amdgcn_alignbit(s0, below, 31) | (s0 & self0) | x0;
-            uint32_t t1 = __builtin_amdgcn_alignbit(s1, s0, 31) | (s1 & self1) | x1;
-            if (any_exc && (x0 | x1)) { acc[2 * lane] = 0; acc[2 * lane + 1] = 0; }
-            s0 = t0 & b.x; s1 = t1 & b.y;
-        }
-        par ^= 1u;
-    }
-};
-
-// One workgroup per stripe; every lane mirrors the (uniform) result bookkeeping, lane 0 writes.
-__global__ __launch_bounds__(1024) void match_stripes_block_kernel(BlockNfaDevice prog, const uint8_t *__restrict__ bytes, size_t nbytes,
-                                                                    uint32_t stripe, const uint64_t *__restrict__ stripe_base,
-                                                                    uint32_t *__restrict__ accept_bits) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    BlockNfa eng;
-    eng.load(prog, smem, true);
-    __syncthreads();
-    const size_t g = blockIdx.x;
-    const size_t start = g * (size_t)stripe;
-    if (start >= nbytes) return;
-    const size_t stripe_end = start + stripe;
-    const size_t my_end = stripe_end < nbytes ? stripe_end : nbytes;
-    const uint64_t my_base = stripe_base[g];
-    const bool fresh = (my_base & kFreshStripe) != 0;
-    uint32_t s0 = (fresh && eng.lane == 0) ? 1u : 0u, s1 = 0;
-    Results res;
-    res.begin(line_of(my_base), !fresh, accept_bits);
-    res.writer = eng.lane == 0;
-    size_t pos = start;
-    for (; pos < my_end; pos++) {
-        const uint32_t c = bytes[pos];
-        if (c == '\n') { res.push(1, eng.accepting(s0, s1) ? 1u : 0u); if (res.bits >> 30) res.flush(); }
-        eng.advance<true>(s0, s1, c);
-    }
-    res.flush();
-    const bool started = fresh || res.seen > 0;
-    if (started && bytes[my_end - 1] != '\n') {
-        bool ended = false;
-        for (; pos < nbytes && !ended; pos++) {
-            const uint32_t c = bytes[pos];
-            if (c == '\n') ended = true;
-            else eng.advance<true>(s0, s1, c);
-        }
-        res.push(1, eng.accepting(s0, s1) ? 1u : 0u);
-    }
-    res.finish();
-}
-__global__ __launch_bounds__(1024) void match_extents_block_kernel(BlockNfaDevice prog, const uint8_t *__restrict__ bytes,
-                                                                    const uint64_t *__restrict__ off, size_t nitems, uint32_t trim,
-                                                                    uint8_t *__restrict__ accept) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    BlockNfa eng;
-    eng.load(prog, smem, false);
-    __syncthreads();
-    const size_t i = blockIdx.x;
-    if (i >= nitems) return;
-    size_t b = off[i], e = off[i + 1];
-    e = e - b >= trim ? e - trim : b;
-    uint32_t s0 = eng.lane == 0 ? 1u : 0u, s1 = 0;
-    for (size_t pos = b; pos < e; pos++) eng.advance<false>(s0, s1, bytes[pos]);
-    const bool ok = eng.accepting(s0, s1);
-    if (eng.lane == 0) accept[i] = ok ? 1 : 0;
-}
-
 }  // namespace
 
 template <int G>
@@ -328,20 +199,6 @@ int match_extents_group_nfa(const GroupNfaDevice &p, const uint8_t *bytes, const
     case 64: return launch_group_extents<64>(p, bytes, off, nitems, trim, accept, stream);
     default: return (int)hipErrorInvalidValue;
     }
-}
-int match_stripes_block_nfa(const BlockNfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
-                            size_t nstripes, uint32_t *accept, void *stream) {
-    if (!nstripes) return 0;
-    hipLaunchKernelGGL(match_stripes_block_kernel, dim3((unsigned)nstripes), dim3(p.T), BlockNfa::lds_bytes(p.T), (hipStream_t)stream, p, bytes, nbytes,
-                       stripe, stripe_base, accept);
-    return (int)hipGetLastError();
-}
-int match_extents_block_nfa(const BlockNfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim, uint8_t *accept,
-                            void *stream) {
-    if (!nitems) return 0;
-    hipLaunchKernelGGL(match_extents_block_kernel, dim3((unsigned)nitems), dim3(p.T), BlockNfa::lds_bytes(p.T), (hipStream_t)stream, p, bytes, off, nitems,
-                       trim, accept);
-    return (int)hipGetLastError();
 }
 // ---- the NFA lane engines are built in four parts by width (kernels_nfa.inc); the entry points pick the part
 #define RRX_NFA_PARTS(name, ARGS_DECL, ARGS)                                                        \

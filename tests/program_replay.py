@@ -6,7 +6,7 @@ import numpy as np
 
 class NfaReplay:
     def __init__(self, words, sparse=False):
-        """sparse: the block-cooperative program (kind 8): CSR arrays xoff[nbits+1], xtgt[] instead of dense rows"""
+        """sparse: the wave-resident program (kind 8): CSR arrays xoff[nbits+1], xtgt[] instead of dense rows"""
         w = [int(x) for x in words]
         self.W, self.nbits, self.n_exc, self.accepts_empty = w[0], w[1], w[2], bool(w[3])
         W, o = self.W, 4

@@ -36,7 +36,7 @@ def test_oversized_automata_are_refused_quickly():
     with pytest.raises(rr.RRegexError, match="too many states"):
         rr.RRegex("(a|b)*a(a|b){20000}")
     assert time.time() - t0 < 20
-    # > 4096 positions and an exploding subset construction: only the block-cooperative engine admits it
+    # > 4096 positions and an exploding subset construction: only the wave-resident engine admits it
     with pytest.raises(rr.RRegexError, match="too large"):
         rr.RRegex("(a|b)*a(a|b){5000}", rr.ENGINE_NFA_WAVE)
     # forcing an engine that cannot hold the automaton is refused as well
@@ -52,5 +52,5 @@ def test_engine_selection_ladder():
     assert rr.RRegex("a{1,300}", rr.ENGINE_DFA).engine_name == "dfa-classed-table"
     assert rr.RRegex("(a|b)*a(a|b){40}").engine_name == "nfa-shift-and"           # 2^41 subsets, 44 positions
     assert rr.RRegex("(a|b)*a(a|b){600}").engine_name == "nfa-group-cooperative"
-    assert rr.RRegex("(a|b)*a(a|b){40}", rr.ENGINE_NFA_BLOCK).engine_name == "nfa-block-cooperative"
+    assert rr.RRegex("(a|b)*a(a|b){40}", rr.ENGINE_NFA_BLOCK).engine_name == "nfa-wave-resident"
     assert rr.RRegex("abc", rr.ENGINE_DFA_GLOBAL).engine_name == "dfa-global-table"

@@ -22,7 +22,7 @@ def _need_gpu():
 
 
 def engines_for(pattern, small=False):
-    """One compiled regex per device engine that admits the automaton.  The group- and block-cooperative NFAs are the
+    """One compiled regex per device engine that admits the automaton.  The group- and wave-resident NFAs are the
     engines of big automata (a whole workgroup per string in the block form), so they only join on small inputs."""
     out = []
     kinds = [rr.ENGINE_NFA, rr.ENGINE_DFA, rr.ENGINE_DFA2, rr.ENGINE_DFA_GLOBAL] + ([rr.ENGINE_NFA_WAVE, rr.ENGINE_NFA_BLOCK] if small else [])
@@ -523,7 +523,7 @@ def test_block_engine_512_lanes():
     the size) - never launched before round 3."""
     p = "(a|b)*a.{17000}"
     assert rr.RRegex(p).words_per_set == 532
-    _coop_engine_case(p, rr.ENGINE_AUTO, "nfa-block-cooperative", (0, 17001, 17002, 17003, 21000), 34,
+    _coop_engine_case(p, rr.ENGINE_AUTO, "nfa-wave-resident", (0, 17001, 17002, 17003, 21000), 34,
                       stripes=(1024, 16384), per_length=1, facade=3, boundary_lines=3, boundary_deltas=(0,))
 
 
@@ -674,11 +674,11 @@ def test_one_shot_entry_reads_the_text_once_and_agrees_with_the_indexed_path():
 
 def test_block_cooperative_engine_beyond_4096_positions():
     """An automaton with more than 4096 positions (5003: no table form exists, beyond the group engine) compiles to the
-    block-cooperative engine and matches the oracle: batch kernel, extents kernel, iterator facade."""
+    wave-resident engine and matches the oracle: batch kernel, extents kernel, iterator facade."""
     rng = random.Random(78)
     p = "(a|b)*a(a|b){5000}"
     r = rr.RRegex(p)
-    assert r.engine_name == "nfa-block-cooperative"
+    assert r.engine_name == "nfa-wave-resident"
     o = OracleRegex(p)
     lines = ["", "a", "a" + "b" * 5000, "b" + "b" * 5000, "ab" * 100 + "a" + "a" * 5000, "a" * 4999, "a" * 5002]
     for n in (5001, 5002, 5600, 9000):

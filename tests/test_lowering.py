@@ -117,14 +117,14 @@ def test_programs_keep_the_language_random():
 
 
 def test_block_program_beyond_4096_positions():
-    """(a|b)*a(a|b){5000}: 5003 positions, no table form, beyond the group engine -> nfa-block-cooperative (the reference's
+    """(a|b)*a(a|b){5000}: 5003 positions, no table form, beyond the group engine -> nfa-wave-resident (the reference's
     Roaring class at any size, Parser.cpp:165).  Its program (exception edges as CSR lists) replays to the oracle's
     answers, in the plain and in the line-mode form; small automata forced onto the engine do too."""
     import numpy as np
     rng = random.Random(43)
     p = "(a|b)*a(a|b){5000}"
     r = rr.RRegex(p)
-    assert r.engine == rr.ENGINE_NFA_BLOCK and r.engine_name == "nfa-block-cooperative"
+    assert r.engine == rr.ENGINE_NFA_BLOCK and r.engine_name == "nfa-wave-resident"
     w = r.program(rr.ENGINE_NFA_BLOCK)
     assert w[1] > 4096
     rep = NfaReplay(w, sparse=True)
