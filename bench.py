@@ -320,6 +320,7 @@ def main():
             "config": {"workload": "BASELINE %s (%d reference states, %s class) over %.2f GiB synthetic lines per GPU"
                                    % (config_name, regex.states_n, "BitSet<%d>" % regex.set_class if regex.set_class else "Roaring", nbytes / 2**30),
                        "pattern_states": regex.states_n, "useful_states": regex.useful_states, "engine": regex.engine_name,
+                       "table_order_profiled_conflicts_before_after": regex.table_order,
                        "bytes_per_gpu": nbytes, "stripe_bytes": corpus.stripe, "lines_per_gpu": nlines, "accepted_rank0": accepted, "sharding": "by lines, no collective"},
             "per_gpu_GBs": round(nbytes * args.steps / elapsed / 1e9, 2),
             "per_rank_GBs": per_rank,

@@ -52,6 +52,12 @@ int         rrx_engine(const rrx_regex *re);       /* RRX_ENGINE_NFA or RRX_ENGI
 const char *rrx_engine_name(const rrx_regex *re);
 uint32_t    rrx_useful_states(const rrx_regex *re);
 uint32_t    rrx_byte_classes(const rrx_regex *re);
+/* 1 if the stride-2 table of this regex is laid out in a PROFILED order: at its first rrx_match_corpus against a corpus of
+ * 64 MiB or more (host work of a few tens of ms, once per regex) the rows and columns of the table are ordered by a 64 KiB
+ * sample of that corpus' text so that fewer of a half-wave's lookups fall into one LDS bank.  *before / *after: the mean
+ * number of distinct entries in the fullest bank per half-wave on that sample (either may be NULL).  Results never depend
+ * on the order.                                                                                                        */
+int         rrx_table_order(const rrx_regex *re, double *conflict_before, double *conflict_after);
 uint32_t    rrx_words_per_set(const rrx_regex *re); /* 32-bit words of the register-resident state set (NFA) */
 int         rrx_accepts_empty(const rrx_regex *re); /* Processor::operator*() on the initial set, NFA.cc:103-107 */
 /* Serialised device program as 32-bit words (layout: DESIGN.md "Device programs"); returns the word count

@@ -22,7 +22,7 @@ PROGRAM_SEARCH_LINE = 9
 ABI_SYMBOLS = (
     "rrx_compile", "rrx_compile_ex", "rrx_free", "rrx_last_error",
     "rrx_num_states", "rrx_set_class", "rrx_ref_initial", "rrx_ref_is_final", "rrx_ref_row",
-    "rrx_engine", "rrx_engine_name", "rrx_useful_states", "rrx_byte_classes", "rrx_words_per_set", "rrx_accepts_empty",
+    "rrx_engine", "rrx_engine_name", "rrx_useful_states", "rrx_byte_classes", "rrx_table_order", "rrx_words_per_set", "rrx_accepts_empty",
     "rrx_program_words",
     "rrx_corpus_create", "rrx_corpus_create_ex", "rrx_corpus_stripe_bytes", "rrx_corpus_num_lines", "rrx_corpus_num_bytes", "rrx_corpus_free", "rrx_corpus_bitmap_words",
     "rrx_match_corpus", "rrx_match_device", "rrx_search_corpus", "rrx_search_all_count", "rrx_search_all_fill", "rrx_search_all", "rrx_bitmap_to_bytes",
@@ -63,6 +63,7 @@ def _load():
         "rrx_engine_name": (C.c_char_p, [vp]),
         "rrx_useful_states": (u32, [vp]),
         "rrx_byte_classes": (u32, [vp]),
+        "rrx_table_order": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "rrx_words_per_set": (u32, [vp]),
         "rrx_accepts_empty": (i32, [vp]),
         "rrx_program_words": (sz, [vp, i32, vp, sz]),
@@ -434,6 +435,13 @@ class RRegex:
     @property
     def useful_states(self):
         return _L.rrx_useful_states(self._h)
+
+    @property
+    def table_order(self):
+        """None, or (before, after): the stride-2 table is laid out in an order profiled on the first large corpus this regex
+        met; the mean number of distinct entries in the fullest LDS bank per half-wave on the sample, as numbered / as ordered."""
+        b, a = C.c_double(0), C.c_double(0)
+        return (b.value, a.value) if _L.rrx_table_order(self._h, C.byref(b), C.byref(a)) else None
 
     @property
     def byte_classes(self):

@@ -104,6 +104,23 @@ struct rrx_regex {
     DfaProgram dfa;
     Dfa2Program dfa2;
     bool has_dfa2 = false;
+    // Order of the stride-2 table's rows and columns in LDS (empty: as numbered).  The order costs no memory and decides which
+    // entries share an LDS bank: bank = (row slot * row words + column slot) mod 32.  State 0 (dead) keeps slot 0.
+    std::vector<uint32_t> t2_row_slot, t2_col_slot;
+    mutable bool t2_order_decided = false;
+    mutable Dfa2OrderStats t2_order_stats;
+    // First match against a corpus that carries a text sample, before any table is uploaded: order the stride-2 table by it
+    // (host work, tens of ms, once per regex).  Only single-copy tables: interleaved copies already keep lanes apart.
+    void decide_t2_order(const uint8_t *sample, uint32_t lanes, uint32_t bytes_per_lane) const {
+        std::lock_guard<std::mutex> lock(mu);
+        if (t2_order_decided || !on_device.empty()) return;
+        t2_order_decided = true;
+        if (!has_dfa2 || !sample || !lanes) return;
+        const uint32_t s2 = dfa2.ncols | 1u;
+        if ((size_t)dfa2.nstates * s2 * 4 * 2 <= dev::kDfa2TableBudget) return;         // two copies fit: the table is replicated instead
+        rrx_regex *self = const_cast<rrx_regex *>(this);
+        t2_order_stats = order_dfa2(dfa2, sample, lanes, bytes_per_lane, self->t2_row_slot, self->t2_col_slot);
+    }
     int engine = 0;
     bool line_wide = false;      // DFA engine: byte-indexed rows (<= kWideMaxStates states) or class-indexed rows
     bool line_global = false;    // DFA engine: class-indexed table too large for LDS, kept in global memory
@@ -426,18 +443,21 @@ struct rrx_regex {
                 while (rep2 < 5 && (size_t)D2 * s2 * 4 * (2u << rep2) <= dev::kDfa2TableBudget && (size_t)C2 * 4 * (2u << rep2) <= 65535) rep2++;
                 const uint32_t R2 = 1u << rep2;
                 std::vector<uint32_t> T2((size_t)D2 * s2 * R2, 0);
+                const bool ordered = t2_row_slot.size() == D2 && t2_col_slot.size() == C2 && t2_row_slot[0] == 0;
+                auto row_slot = [&](uint32_t st) { return ordered ? t2_row_slot[st] : st; };
+                auto col_slot = [&](uint32_t col) { return ordered ? t2_col_slot[col] : col; };
                 for (uint32_t st = 0; st < D2; st++)
                     for (uint32_t col = 0; col < C2; col++) {
                         const uint32_t v = dfa2.next2[(size_t)st * C2 + col];
-                        const uint32_t row_off = (v & 0xffffu) * s2 * 4 * R2;
-                        for (uint32_t k = 0; k < R2; k++) T2[((size_t)st * s2 + col) * R2 + k] = (row_off + 4 * k) | (v & 0xffff0000u);
+                        const uint32_t row_off = row_slot(v & 0xffffu) * s2 * 4 * R2;
+                        for (uint32_t k = 0; k < R2; k++) T2[((size_t)row_slot(st) * s2 + col_slot(col)) * R2 + k] = (row_off + 4 * k) | (v & 0xffff0000u);
                     }
                 std::vector<uint16_t> P(128 * dev::kDfa2PStride, 0);
                 for (unsigned c1 = 0; c1 < 128; c1++)
-                    for (unsigned c2 = 0; c2 < 128; c2++) P[c1 * dev::kDfa2PStride + c2] = (uint16_t)(dfa2.pair_col[c1 * 128 + c2] * 4 * R2);
+                    for (unsigned c2 = 0; c2 < 128; c2++) P[c1 * dev::kDfa2PStride + c2] = (uint16_t)(col_slot(dfa2.pair_col[c1 * 128 + c2]) * 4 * R2);
                 oP2 = put(P.data(), P.size() * 2);
                 oT2 = put(T2.data(), T2.size() * 4);
-                t.dfa2.nrows = D2; t.dfa2.stride = s2 * R2; t.dfa2.start_off = dfa2.start * s2 * 4 * R2; t.dfa2.rep_log2 = rep2;
+                t.dfa2.nrows = D2; t.dfa2.stride = s2 * R2; t.dfa2.start_off = row_slot(dfa2.start) * s2 * 4 * R2; t.dfa2.rep_log2 = rep2;
             }
             t.line.nrows = D; t.line.stride = stride * R; t.line.start_off = dfa.start * row_bytes * R; t.line.wide = wide ? 1 : 0;
             t.line.rep_log2 = rep;
@@ -488,6 +508,11 @@ struct rrx_corpus {
     uint32_t *d_counts = nullptr;   // [nstripes] newlines per stripe, then one flags word
     uint64_t *d_base = nullptr;     // [nstripes+1] exclusive prefix
     bool has_high = false;          // some byte >= 0x80 occurs
+    // A sample of the text as the batch kernel's half-waves see it - the first kSampleBytes bytes of kSampleGroups x 32
+    // consecutive stripes, lane-major, in pinned host memory - taken with the index on large corpora: what a table engine
+    // orders its table by at its first match (order_dfa2).  nullptr: none.
+    uint8_t *h_sample = nullptr;
+    uint32_t sample_lanes = 0;
     // search only: offset of the first byte of every line, built on the first search of this corpus
     mutable std::mutex mu;
     mutable uint64_t *d_line_off = nullptr;     // [nlines + 1]
@@ -496,6 +521,9 @@ struct rrx_corpus {
     mutable size_t nchunks = 0;
     mutable void *d_all_scratch = nullptr;      // rrx_search_all: per-chunk status words, total, ticket (zeroed per call)
 };
+
+static constexpr uint32_t kSampleGroups = 8, kSampleBytes = 256;     // 8 x 32 lanes x 128 pair steps = 1024 half-waves, 64 KiB
+static constexpr size_t kSampleMinCorpus = (size_t)64 << 20;         // smaller corpora: the order search (tens of ms) would not pay
 
 static constexpr size_t kLongStringBytes = 32 * 1024;   // shorter single strings stay on one lane (NFA engines)
 // Table engines: the chunk maps by convergence cost a handful of short launches (60-80 us), a sequential lane 94 ns per byte
@@ -583,6 +611,13 @@ const char *rrx_engine_name(const rrx_regex *re) {
     return re->line_global ? "dfa-global-table" : re->line_wide ? "dfa-wide-table" : "dfa-classed-table";
 }
 uint32_t rrx_useful_states(const rrx_regex *re) { return re->trimmed.n; }
+int rrx_table_order(const rrx_regex *re, double *conflict_before, double *conflict_after) {
+    std::lock_guard<std::mutex> lock(re->mu);
+    const bool profiled = re->t2_row_slot.size() == re->dfa2.nstates && re->has_dfa2 && re->t2_order_stats.half_waves;
+    if (conflict_before) *conflict_before = profiled ? re->t2_order_stats.before : 0.0;
+    if (conflict_after) *conflict_after = profiled ? re->t2_order_stats.after : 0.0;
+    return profiled ? 1 : 0;
+}
 uint32_t rrx_byte_classes(const rrx_regex *re) { return re->trimmed.ncls; }
 uint32_t rrx_words_per_set(const rrx_regex *re) { return re->has_nfa ? re->nfa.W : re->has_wave ? re->nfa_wave.W : re->has_block ? re->nfa_block.W : 0; }
 int rrx_accepts_empty(const rrx_regex *re) {
@@ -664,6 +699,18 @@ int rrx_corpus_create_ex(int device, const void *d_bytes, size_t nbytes, uint32_
     if (rc) { rrx_corpus_free(c); return hip_fail((hipError_t)rc, "line index launch"); }
     MailboxGuard mail;
     if (int mrc = mailbox_acquire(device, &mail.m)) { rrx_corpus_free(c); return mrc; }
+    if (nbytes >= kSampleMinCorpus && c->nstripes >= 64 * kSampleGroups &&
+        hipHostMalloc(reinterpret_cast<void **>(&c->h_sample), (size_t)kSampleGroups * 32 * kSampleBytes, hipHostMallocDefault) == hipSuccess) {
+        c->sample_lanes = kSampleGroups * 32;
+        for (uint32_t g = 0; g < kSampleGroups; g++) {            // group g: 32 consecutive stripes, the groups spread over the corpus
+            const size_t first_stripe = (size_t)g * (c->nstripes / kSampleGroups);
+            if (hipMemcpy2DAsync(c->h_sample + (size_t)g * 32 * kSampleBytes, kSampleBytes, c->d_bytes + first_stripe * c->stripe, c->stripe,
+                                 kSampleBytes, 32, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) {
+                (void)hipGetLastError(); (void)hipHostFree(c->h_sample); c->h_sample = nullptr; c->sample_lanes = 0;
+                break;
+            }
+        }
+    }
     rc = dev::mail_results(c->d_base + c->nstripes, d_flags, nbytes ? c->d_bytes + nbytes - 1 : nullptr, mail.m.dev, stream);
     if (rc) { rrx_corpus_free(c); return hip_fail((hipError_t)rc, "line index launch"); }
     e = hipStreamSynchronize((hipStream_t)stream);
@@ -695,6 +742,7 @@ void rrx_corpus_free(rrx_corpus *c) {
     if (c->d_line_off) (void)hipFree(c->d_line_off);
     if (c->d_chunk_base && c->d_chunk_base != c->d_base) (void)hipFree(c->d_chunk_base);
     if (c->d_all_scratch) (void)hipFree(c->d_all_scratch);
+    if (c->h_sample) (void)hipHostFree(c->h_sample);
     delete c;
 }
 
@@ -702,6 +750,7 @@ size_t rrx_corpus_bitmap_words(const rrx_corpus *c) { return (c->nlines + 31) / 
 
 int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accept_bits, void *stream) {
     if (!re || !c || (c->nlines && !d_accept_bits)) return fail(RRX_ERR_ARG, "null argument");
+    if (!re->t2_order_decided && c->h_sample && !c->has_high) re->decide_t2_order(c->h_sample, c->sample_lanes, kSampleBytes);
     const DeviceTables *t;
     int rc = re->tables(c->device, &t);
     if (rc) return rc;

@@ -78,6 +78,16 @@ struct Dfa2Program {
 };
 // Returns false if there are more than max_cols distinct pair columns.
 bool lower_dfa2(const DfaProgram &d, uint32_t max_cols, Dfa2Program &out);
+// Profile-guided ORDER of the stride-2 table's rows and columns in LDS.  The table's entry for (state s, pair column c) sits at
+// word row_slot[s] * (ncols | 1) + col_slot[c], i.e. in LDS bank (row_slot[s] * (ncols | 1) + col_slot[c]) mod 32: the order
+// costs no memory and decides which entries collide when the 32 lanes of a half-wave look up 32 different (state, column)
+// pairs.  `sample` = the first `bytes_per_lane` bytes of `lanes` consecutive-by-32 stripes of the corpus (lane-major): the
+// lanes of a group are stepped in lockstep, as the kernel steps them, from the dead state (a stripe begins inside somebody's
+// line), and the hottest rows and columns are moved, one swap at a time, to the slots that lower the mean of the worst
+// bank's distinct entries per half-wave.  Returns that mean before and after.  State 0 (dead) keeps slot 0.
+struct Dfa2OrderStats { double before = 0, after = 0; uint32_t half_waves = 0, evaluations = 0; };
+Dfa2OrderStats order_dfa2(const Dfa2Program &d, const uint8_t *sample, uint32_t lanes, uint32_t bytes_per_lane,
+                          std::vector<uint32_t> &row_slot, std::vector<uint32_t> &col_slot);
 
 // The trimmed automaton re-expressed over "positions" (a state split by the character set it is entered on; node 0
 // = the initial state before any input), shrunk by bisimulation quotients and pruning of dominated edges.

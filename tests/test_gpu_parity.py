@@ -357,6 +357,40 @@ def test_full_size_kwlog_config_properties():
     _full_size_properties("kwlog", 4, K1000_CONTAINS, 8 << 30, (rr.ENGINE_DFA2, rr.ENGINE_DFA, rr.ENGINE_NFA), (0, 3, 4098, 8191), (0.2, 0.8))
 
 
+def test_profiled_table_order_changes_no_result():
+    """At its first match against a corpus of 64 MiB or more the stride-2 table is ordered by a sample of the text (rows and
+    columns permuted so that fewer lookups of a half-wave share an LDS bank).  The order must change no result: bit-identical
+    to the byte-stride table engine (which has no such order) and to the oracle on sampled chunks; the sample's conflict
+    figure must not get worse; a regex that met a small corpus first keeps the numbered order."""
+    import synth
+    n = 96 << 20
+    host = synth.corpus("url", 21, n)
+    dev = torch.from_numpy(host).cuda()
+    corpus = rr.Corpus(dev)
+    r = rr.RRegex(U2)
+    assert r.engine_name == "dfa-stride2-table" and r.table_order is None
+    bits = r.match_corpus_bits(corpus).clone()
+    order = r.table_order
+    assert order is not None and order[1] <= order[0] and order[0] > 1.0, order
+    ref = rr.RRegex(U2, rr.ENGINE_DFA).match_corpus_bits(corpus)
+    assert torch.equal(bits, ref)
+    acc = r.match_corpus(corpus).cpu().numpy()
+    o = OracleRegex(U2)
+    chunk = 1 << 20
+    for j in (0, 47, 95):
+        piece = host[j * chunk:(j + 1) * chunk]
+        first = int((host[:j * chunk] == 10).sum())
+        want = o.match_lines(piece)
+        assert (acc[first:first + len(want)] == want).all(), j
+    # the one-shot entry and the search share the regex and must not be disturbed by the order
+    b2, nl = r.match_device_bits(dev)
+    assert nl == corpus.num_lines and torch.equal(b2, bits)
+    small = rr.RRegex(U2)
+    small.match_corpus_bits(rr.Corpus(dev[:1 << 20]))
+    small.match_corpus_bits(corpus)
+    assert small.table_order is None and torch.equal(small.match_corpus_bits(corpus), bits)
+
+
 def test_nul_bytes_in_a_seven_bit_corpus_reach_the_stride2_kernel():
     """A corpus with 0x00 bytes but no byte >= 0x80 keeps the stride-2 engine (has_high stays false): its pair table row
     and column 0 must send the line to the dead state.  All table engines and the NFA, every stripe size."""

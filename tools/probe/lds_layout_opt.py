@@ -59,9 +59,10 @@ freq_s = np.bincount(S[train].ravel(), minlength=D); freq_c = np.bincount(Cc[tra
 print("share of lookups in the 8 hottest rows %.2f, 8 hottest columns %.2f, 32 hottest entries %.2f" % (
     np.sort(freq_s)[-8:].sum() / freq_s.sum(), np.sort(freq_c)[-8:].sum() / freq_c.sum(),
     np.sort(np.bincount((S[train] * C + Cc[train]).ravel()))[-32:].sum() / freq_s.sum()))
+ORDER_ONLY = len(sys.argv) > 3 and sys.argv[3] == "order"
 a, b = a0.copy(), b0.copy()
 best = cost(a, b, tr)
-for it in range(3):
+for it in range(0 if ORDER_ONLY else 3):
     for which, arr, order in (("a", a, np.argsort(-freq_s)), ("b", b, np.argsort(-freq_c))):
         for k in order:
             if (freq_s if which == "a" else freq_c)[k] == 0:
@@ -106,13 +107,13 @@ def prep2(s, c):
     first = np.ones_like(ks, dtype=bool); first[:, 1:] = ks[:, 1:] != ks[:, :-1]
     return np.take_along_axis(s, order, 1), np.take_along_axis(c, order, 1), first
 
-ws, wc = walk_sample(4000)
+ws, wc = walk_sample(4000 if not ORDER_ONLY else 64)
 wtr = prep2(ws, wc)
 fs = np.bincount(ws.ravel(), minlength=D); fc = np.bincount(wc.ravel(), minlength=C)
 a, b = a0.copy(), b0.copy()
 best = cost(a, b, wtr)
 print("automaton walks: %d half-waves, distinct entries %.1f, shipped layout on them %.3f" % (len(ws), wtr[2].sum(1).mean(), best))
-for it in range(2):
+for it in range(0 if ORDER_ONLY else 2):
     for which, arr, order in (("a", a, np.argsort(-fs)), ("b", b, np.argsort(-fc))):
         for k in order:
             if (fs if which == "a" else fc)[k] == 0:
@@ -128,3 +129,78 @@ for it in range(2):
             else:
                 arr[k] = keep
     print("walk-trained pass %d: on walks %.3f  on the real text %.3f" % (it + 1, best, cost(a, b, te)), flush=True)
+
+# ---- what costs no memory: the ORDER of the rows and of the columns.  Row in slot k starts at word k * P (P = C | 1, odd), so its
+# bank residue is k * P mod 32; column in slot j sits at word j.  Search over both permutations by swaps (a row or column tries
+# the slot of the least used row or column of every other residue), trained on `train`, evaluated on the held-out sample.
+P = C | 1
+row_slot = np.arange(D); col_slot = np.arange(C)                  # state 0 (dead) must stay in slot 0
+def ab():
+    return (row_slot * P) & 31, col_slot & 31
+best = cost(*ab(), tr)
+print("order search: start %.3f" % best)
+for it in range(2):
+    for arr, freq, fixed0 in ((row_slot, freq_s, True), (col_slot, freq_c, False)):
+        mult = P if arr is row_slot else 1
+        for k in np.argsort(-freq):
+            if freq[k] == 0 or (fixed0 and k == 0):
+                continue
+            res = (arr * mult) & 31
+            cands = []
+            for r in range(32):
+                if r == res[k]:
+                    continue
+                js = [j for j in np.nonzero(res == r)[0] if not (fixed0 and j == 0)]
+                if js:
+                    cands.append(min(js, key=lambda j: freq[j]))
+            improved = None
+            for j in cands:
+                arr[k], arr[j] = arr[j], arr[k]
+                v = cost(*ab(), tr)
+                if v < best - 1e-9:
+                    best = v; improved = j
+                arr[k], arr[j] = arr[j], arr[k]
+                if improved == j:
+                    pass
+            if improved is not None:
+                j = improved
+                arr[k], arr[j] = arr[j], arr[k]
+                best = cost(*ab(), tr)
+    print("order search pass %d: train %.3f  held-out %.3f" % (it + 1, best, cost(*ab(), te)), flush=True)
+out = os.path.join(ROOT, "tools", "probe", "ab", "t2_order_%s.txt" % wl)
+os.makedirs(os.path.dirname(out), exist_ok=True)
+with open(out, "w") as f:
+    f.write("%d %d\n%s\n%s\n" % (D, C, " ".join(map(str, row_slot)), " ".join(map(str, col_slot))))
+print("wrote", out)
+
+# ---- what the product can afford at first match (a few tens of ms on the host): a small sample, the hottest rows and columns only
+if ORDER_ONLY:
+    for nsamp, top in ((1024, 24), (2048, 32), (1024, 48)):
+        trs = prep(perm[:nsamp])
+        row_slot = np.arange(D); col_slot = np.arange(C)
+        best = cost(*ab(), trs)
+        fs_ = np.bincount(S[perm[:nsamp]].ravel(), minlength=D); fc_ = np.bincount(Cc[perm[:nsamp]].ravel(), minlength=C)
+        evals = 0
+        for arr, freq, fixed0 in ((row_slot, fs_, True), (col_slot, fc_, False)):
+            mult = P if arr is row_slot else 1
+            for k in np.argsort(-freq)[:top]:
+                if freq[k] == 0 or (fixed0 and k == 0):
+                    continue
+                res = (arr * mult) & 31
+                cands = []
+                for r in range(32):
+                    if r == res[k]:
+                        continue
+                    js = [j for j in np.nonzero(res == r)[0] if not (fixed0 and j == 0)]
+                    if js:
+                        cands.append(min(js, key=lambda j: freq[j]))
+                improved = None
+                for j in cands:
+                    arr[k], arr[j] = arr[j], arr[k]
+                    v = cost(*ab(), trs); evals += 1
+                    if v < best - 1e-9:
+                        best = v; improved = j
+                    arr[k], arr[j] = arr[j], arr[k]
+                if improved is not None:
+                    arr[k], arr[improved] = arr[improved], arr[k]
+        print("affordable search: %d half-waves, %d hottest rows and columns, one pass, %d evaluations: train %.3f held-out %.3f" % (nsamp, top, evals, best, cost(*ab(), te)), flush=True)
