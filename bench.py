@@ -41,11 +41,14 @@ WORKLOADS = {
     "nondet": ("ablines", "NONDET", 8 << 30, "extra: (a|b)*a(a|b){40} over lines of a/b (no DFA exists within memory)"),
     "nondet600": ("ablong", "NONDET600", 1 << 30, "extra: (a|b)*a(a|b){600} over lines of 500-900 a/b (604 positions, group-cooperative NFA)"),
     "nondet5000": ("ablong", "NONDET5000", 1 << 28, "extra: (a|b)*a(a|b){5000} over lines of 500-900 a/b (5003 positions, wave-resident NFA)"),
+    # the same automata over SHORT lines (30-120 bytes): only the first block of 2048 positions is ever live - sparse sets
+    "short5000": ("ablines", "NONDET5000", 1 << 28, "extra: (a|b)*a(a|b){5000} over lines of 30-120 a/b (sparse live sets)"),
+    "short16000": ("ablines", "NONDET16000", 1 << 28, "extra: (a|b)*a(a|b){16000} over lines of 30-120 a/b (16003 positions, sparse live sets)"),
 }
 
 
 ENGINES = {"auto": "ENGINE_AUTO", "nfa": "ENGINE_NFA", "dfa": "ENGINE_DFA", "dfa2": "ENGINE_DFA2", "wave": "ENGINE_NFA_WAVE",
-           "dfa-global": "ENGINE_DFA_GLOBAL", "block": "ENGINE_NFA_BLOCK"}
+           "dfa-global": "ENGINE_DFA_GLOBAL", "block": "ENGINE_NFA_BLOCK", "sparse": "ENGINE_NFA_SPARSE"}
 
 
 def patterns():
@@ -54,7 +57,7 @@ def patterns():
     u2 = [k["pattern"] for k in kat["kat"] if k["pattern"].startswith("(http|https|ftp)")][0]
     k1000 = kat["big_states"][-1]["pattern"]
     return {"U2": u2, "EMAIL": r"[A-Za-z0-9._]+@[A-Za-z0-9.]+", "A300": "a{1,300}", "K1000": k1000, "K1000C": ".*(" + k1000 + ").*",
-            "NONDET": "(a|b)*a(a|b){40}", "NONDET600": "(a|b)*a(a|b){600}", "NONDET5000": "(a|b)*a(a|b){5000}"}
+            "NONDET": "(a|b)*a(a|b){40}", "NONDET600": "(a|b)*a(a|b){600}", "NONDET5000": "(a|b)*a(a|b){5000}", "NONDET16000": "(a|b)*a(a|b){16000}"}
 
 
 def traffic_from_profile(workload, nbytes, engine_name):

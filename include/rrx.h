@@ -30,8 +30,12 @@ enum { RRX_OK = 0, RRX_ERR_PATTERN = 1, RRX_ERR_ARG = 2, RRX_ERR_HIP = 3, RRX_ER
 enum { RRX_ENGINE_AUTO = 0, RRX_ENGINE_NFA = 1, RRX_ENGINE_DFA = 2, RRX_ENGINE_DFA_GLOBAL = 3 /* table kept in HBM/L2 */,
        RRX_ENGINE_NFA_WAVE = 4 /* state set spread over 16, 32 or 64 lanes of a wave: up to 4096 positions */,
        RRX_ENGINE_DFA2 = 5 /* table with one dependent lookup per two bytes (AUTO prefers it when it fits) */,
-       RRX_ENGINE_NFA_BLOCK = 8 /* state set spread over a whole workgroup: up to 65536 positions, exception edges as
-                                   sparse lists (the reference's Roaring class, Parser.cpp:165, at any size) */ };
+       RRX_ENGINE_NFA_BLOCK = 8 /* wave-resident NFA: one wave holds one state set of up to 65536 positions (32 words per lane),
+                                   exception edges as sparse lists (the reference's Roaring class, Parser.cpp:165, at any
+                                   size); dense: a byte costs the whole set */,
+       RRX_ENGINE_NFA_SPARSE = 10 /* the same with the set kept as a LIST OF ITS NON-EMPTY BLOCKS of 2048 positions (a bit mask):
+                                   a byte costs the live blocks only (README.md:18-21: sets are sparse) - three times a dense
+                                   word per live block, so for texts on which few blocks are live; never chosen by AUTO */ };
 
 /* ---- compile: RRegex::RRegex(const char*), Parser.cpp:161-170 (host only, no device needed) ---------- */
 int rrx_compile(const char *pattern, rrx_regex **out);

@@ -16,6 +16,7 @@ _SO = os.environ.get("RRX_LIB") or os.path.join(_HERE, "librrx.so")   # RRX_LIB:
 ENGINE_AUTO, ENGINE_NFA, ENGINE_DFA, ENGINE_DFA_GLOBAL, ENGINE_NFA_WAVE, ENGINE_DFA2 = 0, 1, 2, 3, 4, 5
 PROGRAM_SEARCH_FWD, PROGRAM_SEARCH_REV = 6, 7          # rrx_program_words kinds of the two search tables
 ENGINE_NFA_BLOCK = 8
+ENGINE_NFA_SPARSE = 10
 PROGRAM_SEARCH_LINE = 9
 
 # every symbol include/rrx.h declares (tests check the library exports exactly these)

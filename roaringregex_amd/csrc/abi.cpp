@@ -325,11 +325,12 @@ struct rrx_regex {
         size_t oB = 0, oX = 0, oC = 0, oN = 0, oA = 0, oT = 0, oL = 0, oP2 = 0, oT2 = 0;
         size_t oM = 0;
         size_t oCL = 0, oCP = 0, oXI = 0, oXO = 0, oXT = 0;
-        if (engine == RRX_ENGINE_NFA_BLOCK) {
+        if (engine == RRX_ENGINE_NFA_BLOCK || engine == RRX_ENGINE_NFA_SPARSE) {
             // wave-resident form: 64 lanes x WL words, a B row per byte value (+ the line-mode '\n' row), exception edges as CSR
             const uint32_t W = nfa_block.W, N = nfa_block.nbits;
-            const uint32_t WL = dev::wave_words_per_lane(W);
-            const uint32_t WP = 64 * WL;                                 // (word w of the set sits at flat index w: lane w / WL, index w % WL)
+            // (word w of the set sits at flat index w - dense form: lane w / WL, index w % WL; sparse form: row w / 64, lane w % 64)
+            const uint32_t WL = engine == RRX_ENGINE_NFA_SPARSE ? dev::sparse_rows(W) : dev::wave_words_per_lane(W);
+            const uint32_t WP = 64 * WL;
             std::vector<uint32_t> M((size_t)3 * WP, 0), B((size_t)257 * WP, 0);
             const std::vector<uint32_t> *src[3] = {&nfa_block.fin, &nfa_block.self, &nfa_block.excm};
             for (int k = 0; k < 3; k++) for (uint32_t w = 0; w < W; w++) M[(size_t)k * WP + w] = (*src[k])[w];
@@ -343,6 +344,15 @@ struct rrx_regex {
             oXO = put(nfa_block.xoff.data(), nfa_block.xoff.size() * 4);
             oXT = put(xt.data(), xt.size() * 4);
             t.block.WL = WL; t.block.nbits = N;
+            if (engine == RRX_ENGINE_NFA_SPARSE) {                        // rows per byte class too (LDS-resident when they fit)
+                const uint32_t K = trimmed.ncls;
+                std::vector<uint32_t> BC((size_t)K * WP, 0);
+                for (uint32_t k = 1; k < K; k++)
+                    for (uint32_t w = 0; w < W; w++) BC[(size_t)k * WP + w] = nfa_block.B[(size_t)trimmed.cls_rep[k] * W + w];
+                oCL = put(BC.data(), BC.size() * 4);
+                oCP = put(trimmed.cls, 256);
+                t.block.ncls = K;
+            }
             for (uint32_t w = 0; w < W; w++) {
                 if (nfa_block.self[w]) t.block.self_words |= 1u << (w % WL);
                 if (nfa_block.excm[w]) t.block.exc_words |= 1u << (w % WL);
@@ -469,9 +479,10 @@ struct rrx_regex {
             if (up != hipSuccess) { (void)hipFree(t.blob); return hip_fail(up, "device program upload"); }
         }
         const uint8_t *base = static_cast<const uint8_t *>(t.blob);
-        if (engine == RRX_ENGINE_NFA_BLOCK) {
+        if (engine == RRX_ENGINE_NFA_BLOCK || engine == RRX_ENGINE_NFA_SPARSE) {
             t.block.masks = reinterpret_cast<const uint32_t *>(base + oM);
             t.block.Bbyte = reinterpret_cast<const uint32_t *>(base + oB);
+            if (engine == RRX_ENGINE_NFA_SPARSE) { t.block.Bcls = reinterpret_cast<const uint32_t *>(base + oCL); t.block.cls = base + oCP; }
             t.block.xoff = reinterpret_cast<const uint32_t *>(base + oXO);
             t.block.xtgt = reinterpret_cast<const uint32_t *>(base + oXT);
         } else if (engine == RRX_ENGINE_NFA_WAVE) {
@@ -537,7 +548,7 @@ const char *rrx_last_error(void) { return g_err.c_str(); }
 
 int rrx_compile_ex(const char *pattern, int engine, rrx_regex **out) {
     if (!pattern || !out) return fail(RRX_ERR_ARG, "null argument");
-    if (engine < RRX_ENGINE_AUTO || (engine > RRX_ENGINE_DFA2 && engine != RRX_ENGINE_NFA_BLOCK)) return fail(RRX_ERR_ARG, "unknown engine");
+    if (engine < RRX_ENGINE_AUTO || (engine > RRX_ENGINE_DFA2 && engine != RRX_ENGINE_NFA_BLOCK && engine != RRX_ENGINE_NFA_SPARSE)) return fail(RRX_ERR_ARG, "unknown engine");
     *out = nullptr;
     rrx_regex *re = new rrx_regex();
     try {
@@ -546,7 +557,7 @@ int rrx_compile_ex(const char *pattern, int engine, rrx_regex **out) {
         re->trimmed = trim(re->ref);
         const Reduced red = reduce(re->trimmed);
         if (engine == RRX_ENGINE_AUTO || engine == RRX_ENGINE_NFA) re->has_nfa = lower_nfa(red, dev::kMaxNfaWords * 32, re->nfa, /*allow_carry=*/true, /*gaps=*/true);
-        if (engine != RRX_ENGINE_NFA && engine != RRX_ENGINE_NFA_WAVE && engine != RRX_ENGINE_NFA_BLOCK) {     // (DFA, DFA_GLOBAL, DFA2, AUTO)
+        if (engine != RRX_ENGINE_NFA && engine != RRX_ENGINE_NFA_WAVE && engine != RRX_ENGINE_NFA_BLOCK && engine != RRX_ENGINE_NFA_SPARSE) {     // (DFA, DFA_GLOBAL, DFA2, AUTO)
             re->has_dfa = lower_dfa(red, kMaxSubsetStates, re->dfa);
             if (re->has_dfa) {
                 re->line_wide = re->dfa.nstates <= dev::kWideMaxStates && engine != RRX_ENGINE_DFA_GLOBAL;
@@ -564,7 +575,7 @@ int rrx_compile_ex(const char *pattern, int engine, rrx_regex **out) {
         if (engine == RRX_ENGINE_NFA_WAVE || (engine == RRX_ENGINE_AUTO && !re->has_nfa && !re->has_dfa))
             re->has_wave = lower_nfa(red, dev::kGroupMaxBits, re->nfa_wave, /*allow_carry=*/false, /*gaps=*/true);
         // the wave-resident form (any automaton up to 65536 positions): when asked for, or when nothing else took it
-        if (engine == RRX_ENGINE_NFA_BLOCK || (engine == RRX_ENGINE_AUTO && !re->has_nfa && !re->has_dfa && !re->has_wave))
+        if (engine == RRX_ENGINE_NFA_BLOCK || engine == RRX_ENGINE_NFA_SPARSE || (engine == RRX_ENGINE_AUTO && !re->has_nfa && !re->has_dfa && !re->has_wave))
             re->has_block = lower_nfa(red, dev::kBlockMaxBits, re->nfa_block, /*allow_carry=*/false, /*gaps=*/true);
     } catch (const PatternError &e) {
         delete re;
@@ -577,7 +588,7 @@ int rrx_compile_ex(const char *pattern, int engine, rrx_regex **out) {
     if (engine == RRX_ENGINE_NFA) re->engine = re->has_nfa ? RRX_ENGINE_NFA : 0;
     else if (engine == RRX_ENGINE_DFA || engine == RRX_ENGINE_DFA_GLOBAL) re->engine = re->has_dfa ? RRX_ENGINE_DFA : 0;
     else if (engine == RRX_ENGINE_NFA_WAVE) re->engine = re->has_wave ? RRX_ENGINE_NFA_WAVE : 0;
-    else if (engine == RRX_ENGINE_NFA_BLOCK) re->engine = re->has_block ? RRX_ENGINE_NFA_BLOCK : 0;
+    else if (engine == RRX_ENGINE_NFA_BLOCK || engine == RRX_ENGINE_NFA_SPARSE) re->engine = re->has_block ? engine : 0;
     else if (engine == RRX_ENGINE_DFA2) re->engine = re->has_dfa2 ? RRX_ENGINE_DFA : 0;
     else re->engine = (re->has_dfa && !re->line_global) ? RRX_ENGINE_DFA : re->has_nfa ? RRX_ENGINE_NFA : re->has_dfa ? RRX_ENGINE_DFA
                       : re->has_wave ? RRX_ENGINE_NFA_WAVE : re->has_block ? RRX_ENGINE_NFA_BLOCK : 0;
@@ -606,6 +617,7 @@ int rrx_engine(const rrx_regex *re) { return re->engine; }
 const char *rrx_engine_name(const rrx_regex *re) {
     if (re->engine == RRX_ENGINE_NFA_WAVE) return "nfa-group-cooperative";
     if (re->engine == RRX_ENGINE_NFA_BLOCK) return "nfa-wave-resident";
+    if (re->engine == RRX_ENGINE_NFA_SPARSE) return "nfa-wave-sparse";
     if (re->engine != RRX_ENGINE_DFA) return "nfa-shift-and";
     if (re->has_dfa2) return "dfa-stride2-table";      // (the byte-stride table still serves corpora with bytes >= 0x80)
     return re->line_global ? "dfa-global-table" : re->line_wide ? "dfa-wide-table" : "dfa-classed-table";
@@ -630,7 +642,7 @@ size_t rrx_program_words(const rrx_regex *re, int kind, uint32_t *out, size_t ca
         const NfaProgram &p = kind == RRX_ENGINE_NFA ? re->nfa : re->nfa_wave;
         w = {p.W, p.nbits, p.n_exc, p.accepts_empty ? 1u : 0u};
         for (auto *v : {&p.init, &p.fin, &p.chain, &p.self, &p.excm, &p.cgrp, &p.ctgt, &p.B, &p.X}) w.insert(w.end(), v->begin(), v->end());
-    } else if (kind == RRX_ENGINE_NFA_BLOCK && re->has_block) {
+    } else if ((kind == RRX_ENGINE_NFA_BLOCK || kind == RRX_ENGINE_NFA_SPARSE) && re->has_block) {
         const NfaProgram &p = re->nfa_block;
         w = {p.W, p.nbits, p.n_exc, p.accepts_empty ? 1u : 0u};
         for (auto *v : {&p.init, &p.fin, &p.chain, &p.self, &p.excm, &p.cgrp, &p.ctgt, &p.B, &p.xoff, &p.xtgt}) w.insert(w.end(), v->begin(), v->end());
@@ -758,7 +770,9 @@ int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accep
     if (!c->nlines) return RRX_OK;
     // the kernel merges words with atomic OR: start from an all-zero bitmap
     HIP_TRY(hipMemsetAsync(d_accept_bits, 0, rrx_corpus_bitmap_words(c) * sizeof(uint32_t), (hipStream_t)stream));
-    int e = re->engine == RRX_ENGINE_NFA_BLOCK
+    int e = re->engine == RRX_ENGINE_NFA_SPARSE
+                ? dev::match_stripes_sparse_nfa(t->block, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream)
+            : re->engine == RRX_ENGINE_NFA_BLOCK
                 ? dev::match_stripes_wave_nfa(t->block, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream)
             : re->engine == RRX_ENGINE_NFA_WAVE
                 ? dev::match_stripes_group_nfa(t->group, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream)
@@ -1011,7 +1025,8 @@ static constexpr size_t kItemsStripesMinBytes = (size_t)8 << 20;
 // a lane (lane group, workgroup) per item
 static int match_extents_lanes(const rrx_regex *re, const DeviceTables *t, const uint8_t *b, const uint64_t *d_off, size_t nitems, uint32_t trim,
                                uint8_t *d_accept, void *stream, const uint32_t *only_if = nullptr) {
-    int e = re->engine == RRX_ENGINE_NFA_BLOCK ? dev::match_extents_wave_nfa(t->block, b, d_off, nitems, trim, d_accept, stream)
+    int e = re->engine == RRX_ENGINE_NFA_SPARSE ? dev::match_extents_sparse_nfa(t->block, b, d_off, nitems, trim, d_accept, stream)
+            : re->engine == RRX_ENGINE_NFA_BLOCK ? dev::match_extents_wave_nfa(t->block, b, d_off, nitems, trim, d_accept, stream)
             : re->engine == RRX_ENGINE_NFA_WAVE ? dev::match_extents_group_nfa(t->group, b, d_off, nitems, trim, d_accept, stream)
             : re->engine == RRX_ENGINE_NFA ? dev::match_extents_nfa(t->nfa, b, d_off, nitems, trim, d_accept, stream)
                                          : dev::match_extents_dfa(t->dfa, b, d_off, nitems, trim, d_accept, stream, only_if);

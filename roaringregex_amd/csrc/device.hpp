@@ -80,8 +80,18 @@ struct WaveNfaDevice {
                                                  //   row 256 = the line-mode '\n' row {position 0}
     const uint32_t *xoff = nullptr;              // [nbits + 1]
     const uint32_t *xtgt = nullptr;              // targets of position p: xtgt[xoff[p] .. xoff[p+1])
+    uint32_t ncls = 0;                           // sparse form only: the same rows per byte CLASS (for LDS) ...
+    const uint32_t *Bcls = nullptr;              //   [ncls][64 * WL], class 0 = no position
+    const uint8_t *cls = nullptr;                //   [256] byte -> class ('\n' an ordinary byte)
 };
 uint32_t wave_words_per_lane(uint32_t words);    // the instantiated WL that holds `words` 32-bit words (0: too many)
+// The SPARSE form of the same engine (kernels_wave.hip: SparseNfa): WL then counts ROWS of 2048 positions and masks / Bbyte are
+// laid out by rows - [3][WL][64] and [257][WL][64]: word w of the set = row w / 64, lane w % 64.
+uint32_t sparse_rows(uint32_t words);            // the instantiated row count that holds `words` 32-bit words (0: too many)
+int match_stripes_sparse_nfa(const WaveNfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
+                             size_t nstripes, uint32_t *accept_bits, void *stream);
+int match_extents_sparse_nfa(const WaveNfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim,
+                             uint8_t *accept, void *stream);
 
 // Plain DFA (extents kernel: '\n' is an ordinary byte).
 struct DfaDevice {

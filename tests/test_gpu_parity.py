@@ -25,7 +25,7 @@ def engines_for(pattern, small=False):
     """One compiled regex per device engine that admits the automaton.  The group- and wave-resident NFAs are the
     engines of big automata (a whole workgroup per string in the block form), so they only join on small inputs."""
     out = []
-    kinds = [rr.ENGINE_NFA, rr.ENGINE_DFA, rr.ENGINE_DFA2, rr.ENGINE_DFA_GLOBAL] + ([rr.ENGINE_NFA_WAVE, rr.ENGINE_NFA_BLOCK] if small else [])
+    kinds = [rr.ENGINE_NFA, rr.ENGINE_DFA, rr.ENGINE_DFA2, rr.ENGINE_DFA_GLOBAL] + ([rr.ENGINE_NFA_WAVE, rr.ENGINE_NFA_BLOCK, rr.ENGINE_NFA_SPARSE] if small else [])
     for e in kinds:
         try:
             out.append(rr.RRegex(pattern, e))
@@ -561,6 +561,20 @@ def test_block_engine_512_lanes():
                       stripes=(1024, 16384), per_length=1, facade=3, boundary_lines=3, boundary_deltas=(0,))
 
 
+def test_sparse_live_set_engine():
+    """SparseNfa (kernels_wave.hip): the state set kept as the list of its non-empty blocks of 2048 positions (the
+    reference's sets are sparse: README.md:18-21, NFA.cc:77-85).  Rows 1 ... 16: a 604-position automaton (one block), 5003
+    positions (blocks entered by the carry out of the block below), exception edges that reach across blocks, 17003 positions;
+    texts on which one block is live and texts that fill every block."""
+    _coop_engine_case("(a|b)*a(a|b){600}", rr.ENGINE_NFA_SPARSE, "nfa-wave-sparse", (0, 1, 600, 601, 602, 603, 700, 1300), 41)
+    _coop_engine_case("(a|b)*a(a|b){5000}", rr.ENGINE_NFA_SPARSE, "nfa-wave-sparse", (0, 7, 90, 2047, 2048, 2049, 5001, 5002, 5003, 6100, 9000), 42,
+                      stripes=(1024, 16384), boundary_lines=6)
+    _coop_engine_case("((a|b)*a(a|b){2100}c|(b|c)*b(b|c){2500}a)*", rr.ENGINE_NFA_SPARSE, "nfa-wave-sparse",
+                      (0, 3, 2102, 2103, 2502, 2503, 4605, 4606, 5207, 6400), 43, alphabet="abc", stripes=(1024, 16384), facade=2, boundary_lines=6)
+    _coop_engine_case("(a|b)*a.{17000}", rr.ENGINE_NFA_SPARSE, "nfa-wave-sparse", (0, 17001, 17002, 17003, 21000), 34,
+                      stripes=(16384,), per_length=1, facade=2, boundary_lines=2, boundary_deltas=(0,))
+
+
 def test_small_automata_forced_onto_the_cooperative_engines():
     """a{1,300} (BASELINE configs[3]: 301 positions, a pure chain) forced onto the group and block engines over the synthetic
     `arepeat` corpus - batch entry and one-shot entry - and U2 / the email pattern likewise (exception edges, byte
@@ -570,7 +584,7 @@ def test_small_automata_forced_onto_the_cooperative_engines():
         data = synth.corpus(kind, 17, nbytes)
         want = OracleRegex(pattern).match_lines(data)
         dev = torch.from_numpy(data.copy()).cuda()
-        for e in (rr.ENGINE_NFA_WAVE, rr.ENGINE_NFA_BLOCK):
+        for e in (rr.ENGINE_NFA_WAVE, rr.ENGINE_NFA_BLOCK, rr.ENGINE_NFA_SPARSE):
             r = rr.RRegex(pattern, e)
             for stripe in (0, 1024, 16384):
                 got = r.match_corpus(rr.Corpus(dev, stripe=stripe)).cpu().numpy()
