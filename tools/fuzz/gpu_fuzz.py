@@ -24,7 +24,7 @@ while done < npat:
     if o.states_n > 400:
         continue
     engines = []
-    coop = (rr.ENGINE_NFA_WAVE, rr.ENGINE_NFA_BLOCK) if done % 4 == 1 else ()      # the cooperative engines: every 4th pattern
+    coop = (rr.ENGINE_NFA_WAVE, rr.ENGINE_NFA_BLOCK, rr.ENGINE_NFA_SPARSE) if done % 4 == 1 else ()      # the wave-level engines: every 4th pattern
     for e in (rr.ENGINE_NFA, rr.ENGINE_DFA, rr.ENGINE_DFA2, rr.ENGINE_DFA_GLOBAL) + coop:
         try:
             engines.append(rr.RRegex(p, e))
