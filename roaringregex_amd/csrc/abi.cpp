@@ -32,7 +32,7 @@ struct DeviceTables {
     dev::NfaDevice nfa;
     dev::DfaDevice dfa;          // plain form (extents kernel)
     dev::LineDfaDevice line;     // line-mode form (batch kernel)
-    dev::GroupNfaDevice group;   // group-cooperative NFA (16/32/64 lanes per string)
+    dev::GroupNfaDevice group;   // group-cooperative NFA (16/32 lanes per string)
     dev::Dfa2Device dfa2;        // stride-2 line-mode table (corpora without bytes >= 0x80)
     dev::WaveNfaDevice block;    // wave-resident NFA (up to 65536 positions)
 };
@@ -358,24 +358,21 @@ struct rrx_regex {
                 if (nfa_block.excm[w]) t.block.exc_words |= 1u << (w % WL);
             }
         } else if (engine == RRX_ENGINE_NFA_WAVE) {
-            // group-cooperative form: G lanes x 64 positions; B rows per byte CLASS (+ the line-mode '\n' row, last)
+            // group-cooperative form: G lanes x 64 positions; a B row per byte value
             const uint32_t W = nfa_wave.W, N = nfa_wave.nbits;
-            const uint32_t G = N <= 1024 ? 16 : N <= 2048 ? 32 : 64, WP = 2 * G;
-            const uint32_t K = trimmed.ncls + 1;                         // classes of the automaton + the '\n' row
-            std::vector<uint32_t> M((size_t)3 * WP, 0), B((size_t)K * WP, 0);
+            const uint32_t G = N <= 1024 ? 16 : 32, WP = 2 * G;
+            std::vector<uint32_t> M((size_t)3 * WP, 0), B((size_t)256 * WP, 0);
             const std::vector<uint32_t> *src[3] = {&nfa_wave.fin, &nfa_wave.self, &nfa_wave.excm};
             for (int k = 0; k < 3; k++) for (uint32_t w = 0; w < W; w++) M[(size_t)k * WP + w] = (*src[k])[w];
-            for (uint32_t k = 1; k < trimmed.ncls; k++)                   // class 0 stays empty: nothing moves on it
-                for (uint32_t w = 0; w < W; w++) B[(size_t)k * WP + w] = nfa_wave.B[(size_t)trimmed.cls_rep[k] * W + w];
-            B[(size_t)(K - 1) * WP] = 1u;                                 // '\n' in line mode: {position 0}
-            uint8_t cl[256], cp[256];
-            for (int c = 0; c < 256; c++) cl[c] = cp[c] = trimmed.cls[c];
-            cl['\n'] = (uint8_t)(K - 1);
+            for (uint32_t c = 1; c < 128; c++)                            // 0x00 and >= 0x80: empty rows
+                for (uint32_t w = 0; w < W; w++) B[(size_t)c * WP + w] = nfa_wave.B[(size_t)c * W + w];
             std::vector<uint16_t> xidx(N, 0xffff);
             std::vector<uint32_t> X;
             uint32_t rows = 0;
+            bool front = true;
             for (uint32_t b = 0; b < N; b++) {
                 if (!((nfa_wave.excm[b >> 5] >> (b & 31)) & 1u)) continue;
+                if (b >= 32) front = false;
                 xidx[b] = (uint16_t)rows++;
                 X.resize((size_t)rows * WP, 0);
                 for (uint32_t w = 0; w < W; w++) X[(size_t)(rows - 1) * WP + w] = nfa_wave.X[(size_t)b * W + w];
@@ -384,9 +381,9 @@ struct rrx_regex {
             oM = put(M.data(), M.size() * 4);
             oB = put(B.data(), B.size() * 4);
             oX = put(X.data(), X.size() * 4);
-            oCL = put(cl, 256); oCP = put(cp, 256);
             oXI = put(xidx.data(), xidx.size() * 2);
-            t.group.G = G; t.group.nbits = N; t.group.ncls = K; t.group.n_exc = rows;
+            t.group.G = G; t.group.nbits = N; t.group.n_exc = rows;
+            t.group.exc_mode = (rows == 1 && xidx[0] == 0) ? 2 : front ? 1 : 0;
         } else if (engine == RRX_ENGINE_NFA) {
             const uint32_t W = nfa.W, WP = (uint32_t)instantiated_width(W);
             std::vector<uint32_t> B((size_t)256 * WP, 0), X((size_t)nfa.nbits * WP, 0);
@@ -487,9 +484,8 @@ struct rrx_regex {
             t.block.xtgt = reinterpret_cast<const uint32_t *>(base + oXT);
         } else if (engine == RRX_ENGINE_NFA_WAVE) {
             t.group.masks = reinterpret_cast<const uint32_t *>(base + oM);
-            t.group.Bcls = reinterpret_cast<const uint32_t *>(base + oB);
+            t.group.Bbyte = reinterpret_cast<const uint32_t *>(base + oB);
             t.group.X = reinterpret_cast<const uint32_t *>(base + oX);
-            t.group.cls_line = base + oCL; t.group.cls_plain = base + oCP;
             t.group.xidx = reinterpret_cast<const uint16_t *>(base + oXI);
         } else if (engine == RRX_ENGINE_NFA) {
             t.nfa.B = reinterpret_cast<const uint32_t *>(base + oB);

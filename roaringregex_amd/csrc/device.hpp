@@ -53,18 +53,15 @@ struct NfaDevice {                               // tables in HBM (copied to LDS
     const uint32_t *X = nullptr;                 // [nbits][W]
 };
 
-// Group-cooperative NFA (automata beyond kMaxNfaWords*32 positions): the state set is spread over G = 16, 32 or 64
-// neighbouring lanes of a wave, one 64-bit word per lane (1024 / 2048 / 4096 positions); a wave steps 64 / G strings.
-constexpr uint32_t kGroupMaxBits = 4096;
-constexpr size_t kGroupLdsBudget = 64 * 1024;    // class rows of the B table
+// Group-cooperative NFA (automata beyond kMaxNfaWords*32 positions): the state set is spread over G = 16 or 32 neighbouring
+// lanes of a wave, one 64-bit word per lane (1024 / 2048 positions); a wave steps 64 / G strings.
+constexpr uint32_t kGroupMaxBits = 2048;
 struct GroupNfaDevice {
-    uint32_t G = 0, nbits = 0, ncls = 0, n_exc = 0;
+    uint32_t G = 0, nbits = 0, n_exc = 0;
+    uint32_t exc_mode = 0;                       // 0: exception positions anywhere; 1: only in word 0 of the group's lane 0;
+                                                 //   2: position 0 (live on the first byte of a line only) is the only one
     const uint32_t *masks = nullptr;             // [3][G][2]: fin, self, excm
-    const uint32_t *Bcls = nullptr;              // [ncls][G][2]: positions enterable on a byte of the class; class 0 = no
-                                                 //   position (0x00, >= 0x80, bytes outside every label), class ncls-1 = the
-                                                 //   line-mode '\n' row {position 0}
-    const uint8_t *cls_line = nullptr;           // [256] byte -> class, '\n' -> ncls-1 (batch kernel)
-    const uint8_t *cls_plain = nullptr;          // [256] byte -> class, '\n' an ordinary byte (extents kernel)
+    const uint32_t *Bbyte = nullptr;             // [256][G][2]: positions enterable on a byte value (0x00 and >= 0x80: none)
     const uint16_t *xidx = nullptr;              // [nbits] exception row of a position (0xffff: none)
     const uint32_t *X = nullptr;                 // [n_exc][G][2]
 };

@@ -8,61 +8,72 @@ namespace dev {
 namespace {
 
 // ============================================================================================ group-cooperative NFA
-// For automata too large for one lane's registers (513 ... 4096 positions): G = 16, 32 or 64 neighbouring lanes hold ONE
-// state set, lane l of the group the positions [64 l, 64 l + 64) as two 32-bit words, so a wave steps 4, 2 or 1 strings
-// at a time (the first version gave every string a whole wave whatever its automaton's size and read its rows from L2:
-// tens of MB/s).  The same line-mode automaton as the lane engine: a 1 is shifted into position 0 on every byte and only
-// the '\n' row contains position 0; gap positions instead of a CHAIN mask.
+// For automata too large for one lane's registers (513 ... 2048 positions): G = 16 or 32 neighbouring lanes hold ONE state
+// set, lane l of the group the positions [64 l, 64 l + 64) as two 32-bit words, so a wave steps 4 or 2 strings at a time.
+// (Larger automata: one string per wave, kernels_wave.hip.)  Round 3 rebuilt the step after the wave-resident engine:
 //   * text: the lanes of a group load the same 16 bytes (one address per group);
-//   * B rows: per byte CLASS (the '\n' row last), [class][lane of the group] 8-byte words in LDS: consecutive lanes read
-//     consecutive words;
-//   * shift: the word of the lane below arrives by DPP wave_shr:1 (no LDS traffic), the group's lane 0 gets the injected 1;
-//   * exception rows stay in HBM/L2 ([row][lane] words, read coalesced), one live exception position per group and turn:
-//     the loop runs while ANY group of the wave has one left, groups without one idle through it;
+//   * B rows per byte VALUE in LDS, [byte][lane of the group] 8-byte words (32 / 64 KiB): the row address is byte * row
+//     bytes + the lane's offset, no class lookup in front of it;
+//   * shift: the word of the lane below arrives by DPP - row_shr:1 for G = 16 (a group IS a DPP row: its lane 0 gets 0
+//     for free), wave_shr:1 and one select for G = 32;
+//   * nothing is injected per byte: {position 0} is put in place at every line start (the '\n' handling exists anyway),
+//     and a 16-byte chunk in which no group of the wave has a '\n' - lines are long for automata of this size - is
+//     stepped without any per-byte test;
+//   * exception rows stay in HBM/L2 ([row][lane] words, read coalesced), one live exception position per group and turn;
+//     the test for a live one is a single AND + compare when the automaton's exception positions all sit in lane 0's
+//     first word (FRONT: what `.*`-like prefixes and optional heads give);
 //   * verdict: ballot over the group's lanes, only in byte steps where some group of the wave sits on a '\n'.
-template <int G>
+// MODE 0: exception positions anywhere; 1 (FRONT): only in word 0 of the group's lane 0; 2 (INIT): position 0 is the ONLY one.
+// Position 0 is live exactly on the first byte of a line, so in MODE 2 its exception row is ORed in on that byte alone and
+// the per-byte step carries no exception test at all - no compare, no ballot, no branch in the dependent chain.
+template <int G, int MODE>
 struct GroupNfa {
     uint32_t fin0, fin1, self0, self1, exc0, exc1;
-    const uint2 *rows;                     // LDS [ncls][G]
-    const uint8_t *cls;                    // LDS [256]
+    typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
+    lds_u32_ptr rows;                      // LDS [256][G][2], already advanced to this lane
     const uint16_t *__restrict__ xidx;     // HBM/L2 [nbits]: exception row of a position
     const uint2 *__restrict__ X;           // HBM/L2 [n_exc][G]
     bool any_exc;
+    uint32_t x0a = 0, x0b = 0;             // MODE 2: this lane's words of position 0's exception row
     int lane, lig, gbase;                  // lane of the wave, lane of the group, the group's first lane
     uint64_t gmask;                        // the group's lanes in a ballot
 
-    static size_t lds_bytes(const GroupNfaDevice &p) { return (size_t)p.ncls * G * 8 + 256; }
-    __device__ void load(const GroupNfaDevice &p, uint8_t *lds, bool line_mode) {
-        uint32_t *r = reinterpret_cast<uint32_t *>(lds);
-        const int n = (int)(p.ncls * G * 2);
-        for (int i = threadIdx.x; i < n; i += blockDim.x) r[i] = p.Bcls[i];
-        uint8_t *c = lds + (size_t)n * 4;
-        const uint8_t *src = line_mode ? p.cls_line : p.cls_plain;
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) c[i] = src[i];
-        rows = reinterpret_cast<const uint2 *>(lds); cls = c;
+    static size_t lds_bytes(const GroupNfaDevice &) { return (size_t)256 * G * 8; }
+    __device__ void load(const GroupNfaDevice &p, uint8_t *lds) {
+        uint4 *r = reinterpret_cast<uint4 *>(lds);
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.Bbyte);
+        const int n = 256 * G * 8 / 16;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) r[i] = src[i];
         lane = threadIdx.x & 63; lig = lane & (G - 1); gbase = lane - lig;
-        gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << gbase;
+        rows = (lds_u32_ptr)(__attribute__((address_space(3))) uint8_t *)lds + 2 * lig;
+        gmask = ((1ull << G) - 1ull) << gbase;
         const uint2 *m = reinterpret_cast<const uint2 *>(p.masks);
         uint2 v;
         v = m[0 * G + lig]; fin0 = v.x; fin1 = v.y;
         v = m[1 * G + lig]; self0 = v.x; self1 = v.y;
         v = m[2 * G + lig]; exc0 = v.x; exc1 = v.y;
         xidx = p.xidx; X = reinterpret_cast<const uint2 *>(p.X); any_exc = p.n_exc != 0;
+        if (MODE == 2) { const uint2 r0 = X[(size_t)xidx[0] * G + lig]; x0a = r0.x; x0b = r0.y; }
     }
     // every lane of the group must be active
     __device__ __forceinline__ bool accepting(uint32_t s0, uint32_t s1) const {
         return (__ballot(((s0 & fin0) | (s1 & fin1)) != 0) & gmask) != 0;
     }
-    // c is the same in all lanes of a group
-    template <bool LINE>
-    __device__ __forceinline__ void advance(uint32_t &s0, uint32_t &s1, uint32_t c) const {
-        const uint2 b = rows[(uint32_t)cls[c] * G + lig];
-        uint32_t below = __builtin_amdgcn_update_dpp(0u, s1, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-        if (lig == 0) below = LINE ? 0x80000000u : 0u;          // line mode: the 1 shifted into position 0
+    __device__ __forceinline__ void line_start(uint32_t &s0, uint32_t &s1) const { s0 = lig == 0 ? 1u : 0u; s1 = 0; }
+    // c is the same in all lanes of a group (0x00 and >= 0x80: empty rows); first: this is the first byte of a line (MODE 2)
+    __device__ __forceinline__ void advance(uint32_t &s0, uint32_t &s1, uint32_t c, bool first = false) const {
+        const uint2 b = make_uint2(rows[c * (2 * G)], rows[c * (2 * G) + 1]);
+        uint32_t below;
+        if (G == 16) below = __builtin_amdgcn_update_dpp(0u, s1, 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+        else {
+            below = __builtin_amdgcn_update_dpp(0u, s1, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+            if (lig == 0) below = 0u;
+        }
         uint32_t t0 = __builtin_amdgcn_alignbit(s0, below, 31) | (s0 & self0);
         uint32_t t1 = __builtin_amdgcn_alignbit(s1, s0, 31) | (s1 & self1);
-        if (any_exc) {
-            uint32_t e0 = s0 & exc0, e1 = s1 & exc1;
+        if (MODE == 2) { if (first) { t0 |= x0a; t1 |= x0b; } }
+        else if (any_exc) {
+            uint32_t e0 = s0 & exc0, e1 = MODE == 1 ? 0u : s1 & exc1;
             uint64_t live = __ballot((e0 | e1) != 0);            // (scalar: the lanes of the wave with a live exception position)
             while (live) {                                       // the same in every active lane
                 const uint64_t mine = live & gmask;
@@ -83,13 +94,13 @@ struct GroupNfa {
 
 // One group per stripe (the stripe geometry and the result path are the lane kernel's, at group granularity); every
 // lane of a group mirrors the result bookkeeping, its lane 0 alone writes.
-template <int G>
+template <int G, int MODE>
 __global__ __launch_bounds__(256) void match_stripes_group_kernel(GroupNfaDevice prog, const uint8_t *__restrict__ bytes, size_t nbytes,
                                                                    uint32_t stripe, const uint64_t *__restrict__ stripe_base,
                                                                    uint32_t *__restrict__ accept_bits) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    GroupNfa<G> eng;
-    eng.load(prog, smem, true);
+    GroupNfa<G, MODE> eng;
+    eng.load(prog, smem);
     __syncthreads();
     const size_t g = ((size_t)blockIdx.x * 256 + threadIdx.x) / G;
     const size_t start = g * (size_t)stripe;
@@ -98,26 +109,43 @@ __global__ __launch_bounds__(256) void match_stripes_group_kernel(GroupNfaDevice
     const size_t my_end = stripe_end < nbytes ? stripe_end : nbytes;
     const uint64_t my_base = stripe_base[g];
     const bool fresh = (my_base & kFreshStripe) != 0;
-    uint32_t s0 = (fresh && eng.lig == 0) ? 1u : 0u, s1 = 0;   // not fresh: dead until the first '\n'
+    uint32_t s0, s1;
+    eng.line_start(s0, s1);
+    bool first = fresh;                                        // the next byte is the first of a line (the same in all lanes of a group)
+    if (!fresh) s0 = 0;                                        // inside somebody else's line: dead until the first '\n'
     Results res;
     res.begin(line_of(my_base), !fresh, accept_bits);
     res.writer = eng.lig == 0;
 
     auto one = [&](uint32_t c) {
         const bool isnl = c == '\n';
+        uint32_t a0 = s0, a1 = s1;
+        eng.advance(a0, a1, c, first);
+        first = false;
         if (__ballot(isnl)) {                                  // some group of the wave ends a line on this byte
             const bool a = eng.accepting(s0, s1);
-            if (isnl) { res.push(1, a ? 1u : 0u); if (res.bits >> 30) res.flush(); }
+            if (isnl) { res.push(1, a ? 1u : 0u); if (res.bits >> 30) res.flush(); eng.line_start(a0, a1); first = true; }
         }
-        eng.template advance<true>(s0, s1, c);
+        s0 = a0; s1 = a1;
     };
     // ---- the lines inside my stripe: stripes are multiples of 16 bytes, only the corpus end leaves a tail
     size_t pos = start;
     for (; pos + 16 <= my_end; pos += 16) {
         const uint4 v = *reinterpret_cast<const uint4 *>(bytes + pos);
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t nl = 0;                                       // exact zero-byte test on w ^ 0x0a0a0a0a
 #pragma unroll
-        for (int k = 0; k < 16; k++) one((w[k >> 2] >> (8 * (k & 3))) & 0xffu);
+        for (int q = 0; q < 4; q++) { const uint32_t x = w[q] ^ 0x0a0a0a0au; nl |= ~(((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x | 0x7f7f7f7fu); }
+        if (!__ballot(nl != 0 || (MODE == 2 && first))) {      // no group of the wave meets a '\n' in its 16 bytes (or stands at a line start)
+#pragma unroll
+            for (int k = 0; k < 16; k++) eng.advance(s0, s1, (w[k >> 2] >> (8 * (k & 3))) & 0xffu);
+        } else {
+#pragma unroll 1
+            for (int k = 0; k < 16; k++) {
+                const uint32_t wk = k < 8 ? (k < 4 ? v.x : v.y) : (k < 12 ? v.z : v.w);
+                one((wk >> (8 * (k & 3))) & 0xffu);
+            }
+        }
     }
     for (; pos < my_end; pos++) one(bytes[pos]);
     res.flush();
@@ -126,80 +154,90 @@ __global__ __launch_bounds__(256) void match_stripes_group_kernel(GroupNfaDevice
     const bool started = fresh || res.seen > 0;
     if (started && bytes[my_end - 1] != '\n') {
         bool ended = false;
+        // 16 bytes per load (pos is 16-byte aligned here unless the corpus ended inside my stripe): one byte per load was a
+        // chain of memory round trips as long as half a line - 350 bytes on the 500-900 byte lines these automata are for
+        while (!ended && !(pos & 15) && pos + 16 <= nbytes) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(bytes + pos);
+#pragma unroll 1
+            for (int k = 0; k < 16 && !ended; k++) {
+                const uint32_t wk = k < 8 ? (k < 4 ? v.x : v.y) : (k < 12 ? v.z : v.w);
+                const uint32_t c = (wk >> (8 * (k & 3))) & 0xffu;
+                if (c == '\n') ended = true;
+                else { eng.advance(s0, s1, c, first); first = false; }
+            }
+            pos += 16;
+        }
         for (; pos < nbytes && !ended; pos++) {
             const uint32_t c = bytes[pos];
             if (c == '\n') ended = true;
-            else eng.template advance<true>(s0, s1, c);
+            else { eng.advance(s0, s1, c, first); first = false; }
         }
         res.push(1, eng.accepting(s0, s1) ? 1u : 0u);          // '\n' or the end of the corpus ends the line
     }
     res.finish();
 }
 
-// One group per explicit item ('\n' ordinary: the plain class table, nothing shifted into position 0).
-template <int G>
+// One group per explicit item ('\n' an ordinary byte).
+template <int G, int MODE>
 __global__ __launch_bounds__(256) void match_extents_group_kernel(GroupNfaDevice prog, const uint8_t *__restrict__ bytes,
                                                                    const uint64_t *__restrict__ off, size_t nitems, uint32_t trim,
                                                                    uint8_t *__restrict__ accept) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    GroupNfa<G> eng;
-    eng.load(prog, smem, false);
+    GroupNfa<G, MODE> eng;
+    eng.load(prog, smem);
     __syncthreads();
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) / G;
     if (i >= nitems) return;
     size_t b = off[i], e = off[i + 1];
     e = e - b >= trim ? e - trim : b;
-    uint32_t s0 = eng.lig == 0 ? 1u : 0u, s1 = 0;
-    for (size_t pos = b; pos < e; pos++) eng.template advance<false>(s0, s1, bytes[pos]);      // 0x00 and >= 0x80: empty rows
+    uint32_t s0, s1;
+    eng.line_start(s0, s1);
+    for (size_t pos = b; pos < e; pos++) eng.advance(s0, s1, bytes[pos], pos == b);
     const bool ok = eng.accepting(s0, s1);
     if (eng.lig == 0) accept[i] = ok ? 1 : 0;
 }
 
 }  // namespace
 
-template <int G>
+template <int G, int MODE>
 static int launch_group_stripes(const GroupNfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
                                 size_t nstripes, uint32_t *accept, void *stream) {
-    const size_t lds = GroupNfa<G>::lds_bytes(p);
+    const size_t lds = GroupNfa<G, MODE>::lds_bytes(p);
     static LdsAttr attr;
-    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(match_stripes_group_kernel<G>), lds);
+    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(match_stripes_group_kernel<G, MODE>), lds);
     if (e != hipSuccess) return (int)e;
     const size_t per_block = 256 / G, blocks = (nstripes + per_block - 1) / per_block;
-    hipLaunchKernelGGL(match_stripes_group_kernel<G>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept);
+    hipLaunchKernelGGL((match_stripes_group_kernel<G, MODE>), dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept);
     return (int)hipGetLastError();
 }
-template <int G>
+template <int G, int MODE>
 static int launch_group_extents(const GroupNfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim, uint8_t *accept,
                                 void *stream) {
-    const size_t lds = GroupNfa<G>::lds_bytes(p);
+    const size_t lds = GroupNfa<G, MODE>::lds_bytes(p);
     static LdsAttr attr;
-    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(match_extents_group_kernel<G>), lds);
+    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(match_extents_group_kernel<G, MODE>), lds);
     if (e != hipSuccess) return (int)e;
     const size_t per_block = 256 / G, blocks = (nitems + per_block - 1) / per_block;
-    hipLaunchKernelGGL(match_extents_group_kernel<G>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p, bytes, off, nitems, trim, accept);
+    hipLaunchKernelGGL((match_extents_group_kernel<G, MODE>), dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)stream, p, bytes, off, nitems, trim, accept);
     return (int)hipGetLastError();
 }
+#define RRX_GROUP_DISPATCH(FN, ...)                                                                      \
+    switch (p.G * 4 + p.exc_mode) {                                                                      \
+    case 16 * 4 + 0: return FN<16, 0>(__VA_ARGS__); case 16 * 4 + 1: return FN<16, 1>(__VA_ARGS__); case 16 * 4 + 2: return FN<16, 2>(__VA_ARGS__); \
+    case 32 * 4 + 0: return FN<32, 0>(__VA_ARGS__); case 32 * 4 + 1: return FN<32, 1>(__VA_ARGS__); case 32 * 4 + 2: return FN<32, 2>(__VA_ARGS__); \
+    default: return (int)hipErrorInvalidValue;                                                           \
+    }
 int match_stripes_group_nfa(const GroupNfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
                             size_t nstripes, uint32_t *accept, void *stream) {
     if (!nstripes) return 0;
-    if (GroupNfa<64>::lds_bytes(p) > kGroupLdsBudget) return (int)hipErrorInvalidValue;
-    switch (p.G) {
-    case 16: return launch_group_stripes<16>(p, bytes, nbytes, stripe, stripe_base, nstripes, accept, stream);
-    case 32: return launch_group_stripes<32>(p, bytes, nbytes, stripe, stripe_base, nstripes, accept, stream);
-    case 64: return launch_group_stripes<64>(p, bytes, nbytes, stripe, stripe_base, nstripes, accept, stream);
-    default: return (int)hipErrorInvalidValue;
-    }
+    RRX_GROUP_DISPATCH(launch_group_stripes, p, bytes, nbytes, stripe, stripe_base, nstripes, accept, stream)
 }
 int match_extents_group_nfa(const GroupNfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim, uint8_t *accept,
                             void *stream) {
     if (!nitems) return 0;
-    switch (p.G) {
-    case 16: return launch_group_extents<16>(p, bytes, off, nitems, trim, accept, stream);
-    case 32: return launch_group_extents<32>(p, bytes, off, nitems, trim, accept, stream);
-    case 64: return launch_group_extents<64>(p, bytes, off, nitems, trim, accept, stream);
-    default: return (int)hipErrorInvalidValue;
-    }
+    RRX_GROUP_DISPATCH(launch_group_extents, p, bytes, off, nitems, trim, accept, stream)
 }
+#undef RRX_GROUP_DISPATCH
 // ---- the NFA lane engines are built in four parts by width (kernels_nfa.inc); the entry points pick the part
 #define RRX_NFA_PARTS(name, ARGS_DECL, ARGS)                                                        \
     int name##_part0 ARGS_DECL; int name##_part1 ARGS_DECL; int name##_part2 ARGS_DECL; int name##_part3 ARGS_DECL; \

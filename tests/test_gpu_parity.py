@@ -539,13 +539,13 @@ def _coop_engine_case(pattern, engine, engine_name, lengths, seed, alphabet="ab"
         assert (r.get_acceptance_iter(t).advance().value() is not None) == bool(want(t)), (pattern[:30], "facade", len(t))
 
 
-def test_group_engine_32_and_64_lanes_per_string():
+def test_group_engine_32_lanes_per_string_and_beyond():
     """match_stripes_group_kernel<32> (1025-2048 positions: two strings per wave, wave_shr:1 carries a word across a DPP
-    row boundary) and <64> (2049-4096: one string per wave), with their extents forms - never launched before round 3.
+    row boundary), with its extents form; beyond 2048 positions a string takes a whole wave (the wave-resident engine).
     Reference: any automaton size, Parser.cpp:165; the loop, NFA.cc:77-85."""
     _coop_engine_case("(a|b)*a(a|b){1500}", rr.ENGINE_AUTO, "nfa-group-cooperative", (0, 1, 1500, 1501, 1502, 1503, 1600, 2100, 3300, 5000), 31)
     assert rr.RRegex("(a|b)*a(a|b){1500}").words_per_set == 47
-    _coop_engine_case("(a|b)*a(a|b){3000}", rr.ENGINE_AUTO, "nfa-group-cooperative", (0, 2, 3000, 3001, 3002, 3003, 3100, 4200, 6100, 9000), 32)
+    _coop_engine_case("(a|b)*a(a|b){3000}", rr.ENGINE_AUTO, "nfa-wave-resident", (0, 2, 3000, 3001, 3002, 3003, 3100, 4200, 6100, 9000), 32)
     assert rr.RRegex("(a|b)*a(a|b){3000}").words_per_set == 94
     # exception edges reaching across lanes and rows of the group (not just the add-one chain)
     _coop_engine_case("((a|b)*a(a|b){700}c|(b|c)*b(b|c){800}a)*", rr.ENGINE_NFA_WAVE, "nfa-group-cooperative",
