@@ -62,6 +62,10 @@ uint32_t    rrx_byte_classes(const rrx_regex *re);
  * number of distinct entries in the fullest bank per half-wave on that sample (either may be NULL).  Results never depend
  * on the order.                                                                                                        */
 int         rrx_table_order(const rrx_regex *re, double *conflict_before, double *conflict_after);
+/* The same ordering from a text sample the CALLER provides (host memory), before the regex' first match: `lanes` (a multiple of
+ * 32) pieces of `bytes_per_lane` bytes each, lane-major - 32 consecutive pieces are stepped in lockstep the way a half-wave
+ * steps 32 neighbouring stripes, so take them from 32 places of the text a stripe (some KiB) apart.  Host only.              */
+int         rrx_order_table(rrx_regex *re, const void *sample, uint32_t lanes, uint32_t bytes_per_lane);
 uint32_t    rrx_words_per_set(const rrx_regex *re); /* 32-bit words of the register-resident state set (NFA) */
 int         rrx_accepts_empty(const rrx_regex *re); /* Processor::operator*() on the initial set, NFA.cc:103-107 */
 /* Serialised device program as 32-bit words (layout: DESIGN.md "Device programs"); returns the word count
@@ -70,6 +74,8 @@ int         rrx_accepts_empty(const rrx_regex *re); /* Processor::operator*() on
  * layout); 0 if that form was not built.                                                                      */
 #define RRX_PROGRAM_SEARCH_FWD 6   /* "any bytes, then the pattern": accepting where a match ends              */
 #define RRX_PROGRAM_SEARCH_REV 7   /* the pattern right to left: accepting where a match starts                */
+#define RRX_PROGRAM_DFA2_ORDER 11  /* [nstates, ncols, row_slot[nstates], col_slot[ncols]]: the stride-2 table's profiled order
+                                      (0 words while the table is laid out as numbered)                                  */
 #define RRX_PROGRAM_SEARCH_LINE 9  /* the forward table as the stripe-wise search kernel runs it: [nrows, ncols, start row,
                                       SKIP row, column of byte[256], entry[nrows][ncols]], entry = next row | '\n' << 16 |
                                       hit << 17 | match-starts-at-the-line-start << 18 (0 words: form not available)   */

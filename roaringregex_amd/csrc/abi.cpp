@@ -619,6 +619,16 @@ const char *rrx_engine_name(const rrx_regex *re) {
     return re->line_global ? "dfa-global-table" : re->line_wide ? "dfa-wide-table" : "dfa-classed-table";
 }
 uint32_t rrx_useful_states(const rrx_regex *re) { return re->trimmed.n; }
+int rrx_order_table(rrx_regex *re, const void *sample, uint32_t lanes, uint32_t bytes_per_lane) {
+    if (!re || !sample || lanes < 32 || bytes_per_lane < 2) return fail(RRX_ERR_ARG, "sample: at least 32 lanes of 2 bytes");
+    {
+        std::lock_guard<std::mutex> lock(re->mu);
+        if (!re->on_device.empty()) return fail(RRX_ERR_ARG, "the tables are already on a device: order the table before the first match");
+        if (re->t2_order_decided) return fail(RRX_ERR_ARG, "the table order has been decided already");
+    }
+    re->decide_t2_order(static_cast<const uint8_t *>(sample), lanes, bytes_per_lane);
+    return RRX_OK;
+}
 int rrx_table_order(const rrx_regex *re, double *conflict_before, double *conflict_after) {
     std::lock_guard<std::mutex> lock(re->mu);
     const bool profiled = re->t2_row_slot.size() == re->dfa2.nstates && re->has_dfa2 && re->t2_order_stats.half_waves;
@@ -649,6 +659,12 @@ size_t rrx_program_words(const rrx_regex *re, int kind, uint32_t *out, size_t ca
         w = {d.nrows, d.ncols, d.start, d.skip};
         for (int c = 0; c < 256; c++) w.push_back(c == '\n' ? d.ncols - 1 : re->search_fwd.cls[c]);
         w.insert(w.end(), d.table.begin(), d.table.end());
+    } else if (kind == RRX_PROGRAM_DFA2_ORDER && re->has_dfa2) {
+        std::lock_guard<std::mutex> lock(re->mu);
+        if (re->t2_row_slot.size() != re->dfa2.nstates || re->t2_col_slot.size() != re->dfa2.ncols) return 0;
+        w = {re->dfa2.nstates, re->dfa2.ncols};
+        w.insert(w.end(), re->t2_row_slot.begin(), re->t2_row_slot.end());
+        w.insert(w.end(), re->t2_col_slot.begin(), re->t2_col_slot.end());
     } else if (kind == RRX_ENGINE_DFA2 && re->has_dfa2) {
         const Dfa2Program &d = re->dfa2;
         w = {d.nstates, d.ncols, d.start, d.accepts_empty ? 1u : 0u};
