@@ -249,6 +249,12 @@ def main():
     for _ in range(8):
         regex.match_corpus_bits(corpus, out=out)
     torch.cuda.synchronize()
+    # (a stride-2 table that is not replicated is being ordered by a background thread since the first match - tens of ms of
+    # host work, DESIGN.md 4.7 - and swapped in when done: the steady state this bench measures begins then)
+    t_wait = time.perf_counter()
+    while regex.table_order_pending and time.perf_counter() - t_wait < 1.0:
+        time.sleep(0.01)
+    order_wait_ms = (time.perf_counter() - t_wait) * 1e3
     # one-shot ("cold") rate: a corpus nobody has indexed yet — index build + one match, clocks warm, HIP events
     e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
     cold = []
@@ -323,7 +329,7 @@ def main():
             "config": {"workload": "BASELINE %s (%d reference states, %s class) over %.2f GiB synthetic lines per GPU"
                                    % (config_name, regex.states_n, "BitSet<%d>" % regex.set_class if regex.set_class else "Roaring", nbytes / 2**30),
                        "pattern_states": regex.states_n, "useful_states": regex.useful_states, "engine": regex.engine_name,
-                       "table_order_profiled_conflicts_before_after": regex.table_order,
+                       "table_order_profiled_conflicts_before_after": regex.table_order, "table_order_wait_ms": round(order_wait_ms, 1),
                        "bytes_per_gpu": nbytes, "stripe_bytes": corpus.stripe, "lines_per_gpu": nlines, "accepted_rank0": accepted, "sharding": "by lines, no collective"},
             "per_gpu_GBs": round(nbytes * args.steps / elapsed / 1e9, 2),
             "per_rank_GBs": per_rank,

@@ -56,9 +56,11 @@ int         rrx_engine(const rrx_regex *re);       /* RRX_ENGINE_NFA or RRX_ENGI
 const char *rrx_engine_name(const rrx_regex *re);
 uint32_t    rrx_useful_states(const rrx_regex *re);
 uint32_t    rrx_byte_classes(const rrx_regex *re);
-/* 1 if the stride-2 table of this regex is laid out in a PROFILED order: at its first rrx_match_corpus against a corpus of
- * 64 MiB or more (host work of a few tens of ms, once per regex) the rows and columns of the table are ordered by a 64 KiB
- * sample of that corpus' text so that fewer of a half-wave's lookups fall into one LDS bank.  *before / *after: the mean
+/* 1 if the stride-2 table of this regex is laid out in a PROFILED order, 2 while the search for one is running, else 0.  At a
+ * regex' first rrx_match_corpus against a corpus of 64 MiB or more a background thread (tens of ms of host work, once per
+ * regex; tables small enough to be replicated are left alone) orders the rows and columns of the table by a 64 KiB sample of
+ * that corpus' text so that fewer of a half-wave's lookups fall into one LDS bank, and swaps the tables in when it is done:
+ * no call waits for it, launches before the swap run on the table as numbered.  *before / *after: the mean
  * number of distinct entries in the fullest bank per half-wave on that sample (either may be NULL).  Results never depend
  * on the order.                                                                                                        */
 int         rrx_table_order(const rrx_regex *re, double *conflict_before, double *conflict_after);

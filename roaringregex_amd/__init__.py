@@ -453,7 +453,12 @@ class RRegex:
         """None, or (before, after): the stride-2 table is laid out in an order profiled on the first large corpus this regex
         met; the mean number of distinct entries in the fullest LDS bank per half-wave on the sample, as numbered / as ordered."""
         b, a = C.c_double(0), C.c_double(0)
-        return (b.value, a.value) if _L.rrx_table_order(self._h, C.byref(b), C.byref(a)) else None
+        return (b.value, a.value) if _L.rrx_table_order(self._h, C.byref(b), C.byref(a)) == 1 else None
+
+    @property
+    def table_order_pending(self):
+        """True while the background search for a profiled table order is running."""
+        return _L.rrx_table_order(self._h, None, None) == 2
 
     @property
     def byte_classes(self):

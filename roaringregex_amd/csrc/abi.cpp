@@ -1,11 +1,13 @@
 // abi.cpp — the C ABI of librrx.so (include/rrx.h): host compile pipeline + device program upload + launches.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/rrx.h"
@@ -107,20 +109,80 @@ struct rrx_regex {
     // Order of the stride-2 table's rows and columns in LDS (empty: as numbered).  The order costs no memory and decides which
     // entries share an LDS bank: bank = (row slot * row words + column slot) mod 32.  State 0 (dead) keeps slot 0.
     std::vector<uint32_t> t2_row_slot, t2_col_slot;
-    mutable bool t2_order_decided = false;
+    mutable std::atomic<bool> t2_order_decided{false}, t2_order_done{false};
     mutable Dfa2OrderStats t2_order_stats;
-    // First match against a corpus that carries a text sample, before any table is uploaded: order the stride-2 table by it
-    // (host work, tens of ms, once per regex).  Only single-copy tables: interleaved copies already keep lanes apart.
-    void decide_t2_order(const uint8_t *sample, uint32_t lanes, uint32_t bytes_per_lane) const {
-        std::lock_guard<std::mutex> lock(mu);
-        if (t2_order_decided || !on_device.empty()) return;
-        t2_order_decided = true;
-        if (!has_dfa2 || !sample || !lanes) return;
-        const uint32_t s2 = dfa2.ncols | 1u;
-        if ((size_t)dfa2.nstates * s2 * 4 * 2 <= dev::kDfa2TableBudget) return;         // two copies fit: the table is replicated instead
-        rrx_regex *self = const_cast<rrx_regex *>(this);
-        t2_order_stats = order_dfa2(dfa2, sample, lanes, bytes_per_lane, self->t2_row_slot, self->t2_col_slot);
+    mutable std::thread t2_order_thread;                 // the background order search (joined by the destructor)
+    mutable std::vector<std::pair<int, void *>> t2_extra_blobs;      // tables uploaded again in the profiled order (device, blob)
+    // The stride-2 tables as they go to the device, in the current order: T2 rows of `ncols | 1` entries (odd), R interleaved
+    // copies, entry = LDS byte offset of the next row | lines << 16 | verdicts << 24; P = pair -> byte offset of its column.
+    void build_dfa2_arrays(std::vector<uint32_t> &T2, std::vector<uint16_t> &P, dev::Dfa2Device &d) const {      // call with `mu` held
+        const uint32_t D2 = dfa2.nstates, C2 = dfa2.ncols;
+        const uint32_t s2 = C2 | 1u;
+        uint32_t rep2 = 0;
+        while (rep2 < 5 && (size_t)D2 * s2 * 4 * (2u << rep2) <= dev::kDfa2TableBudget && (size_t)C2 * 4 * (2u << rep2) <= 65535) rep2++;
+        const uint32_t R2 = 1u << rep2;
+        T2.assign((size_t)D2 * s2 * R2, 0);
+        const bool ordered = t2_row_slot.size() == D2 && t2_col_slot.size() == C2 && t2_row_slot[0] == 0;
+        auto row_slot = [&](uint32_t st) { return ordered ? t2_row_slot[st] : st; };
+        auto col_slot = [&](uint32_t col) { return ordered ? t2_col_slot[col] : col; };
+        for (uint32_t st = 0; st < D2; st++)
+            for (uint32_t col = 0; col < C2; col++) {
+                const uint32_t v = dfa2.next2[(size_t)st * C2 + col];
+                const uint32_t row_off = row_slot(v & 0xffffu) * s2 * 4 * R2;
+                for (uint32_t k = 0; k < R2; k++) T2[((size_t)row_slot(st) * s2 + col_slot(col)) * R2 + k] = (row_off + 4 * k) | (v & 0xffff0000u);
+            }
+        P.assign(128 * dev::kDfa2PStride, 0);
+        for (unsigned c1 = 0; c1 < 128; c1++)
+            for (unsigned c2 = 0; c2 < 128; c2++) P[c1 * dev::kDfa2PStride + c2] = (uint16_t)(col_slot(dfa2.pair_col[c1 * 128 + c2]) * 4 * R2);
+        d.nrows = D2; d.stride = s2 * R2; d.start_off = row_slot(dfa2.start) * s2 * 4 * R2; d.rep_log2 = rep2;
     }
+    bool t2_order_applies() const {                      // single-copy tables only: interleaved copies already keep lanes apart
+        return has_dfa2 && (size_t)dfa2.nstates * (dfa2.ncols | 1u) * 4 * 2 > dev::kDfa2TableBudget;
+    }
+    // The order search itself (tens of ms of host work) and, for devices whose tables are already up, a second upload of the
+    // stride-2 arrays in the new order; launches pick the descriptor up under `mu` (dfa2_device), so they see either set whole.
+    void run_t2_order(std::vector<uint8_t> sample, uint32_t lanes, uint32_t bytes_per_lane) const {
+        std::vector<uint32_t> rows, cols;
+        const Dfa2OrderStats st = order_dfa2(dfa2, sample.data(), lanes, bytes_per_lane, rows, cols);
+        std::lock_guard<std::mutex> lock(mu);
+        rrx_regex *self = const_cast<rrx_regex *>(this);
+        self->t2_row_slot.swap(rows); self->t2_col_slot.swap(cols);
+        t2_order_stats = st;
+        for (auto &kv : on_device) {
+            std::vector<uint32_t> T2;
+            std::vector<uint16_t> P;
+            dev::Dfa2Device d = kv.second.dfa2;
+            build_dfa2_arrays(T2, P, d);
+            const size_t pb = (P.size() * 2 + 15) & ~(size_t)15;
+            void *blob = nullptr;
+            hipStream_t st2 = nullptr;
+            bool ok = hipSetDevice(kv.first) == hipSuccess && hipMalloc(&blob, pb + T2.size() * 4) == hipSuccess &&
+                      hipStreamCreateWithFlags(&st2, hipStreamNonBlocking) == hipSuccess;
+            if (ok) ok = hipMemcpyAsync(blob, P.data(), P.size() * 2, hipMemcpyHostToDevice, st2) == hipSuccess &&
+                         hipMemcpyAsync(static_cast<uint8_t *>(blob) + pb, T2.data(), T2.size() * 4, hipMemcpyHostToDevice, st2) == hipSuccess &&
+                         hipStreamSynchronize(st2) == hipSuccess;
+            if (st2) (void)hipStreamDestroy(st2);
+            if (!ok) { (void)hipGetLastError(); if (blob) (void)hipFree(blob); continue; }       // (that device keeps the numbered order)
+            t2_extra_blobs.emplace_back(kv.first, blob);
+            d.P = static_cast<const uint16_t *>(blob);
+            d.T2 = reinterpret_cast<const uint32_t *>(static_cast<uint8_t *>(blob) + pb);
+            kv.second.dfa2 = d;
+        }
+        t2_order_done = true;
+    }
+    // First match against a corpus that carries a text sample: start the search in the background (the match itself, and the
+    // next ones, run on the table as numbered until the new order is in).  `now`: run it in the caller's thread (rrx_order_table).
+    void decide_t2_order(const uint8_t *sample, uint32_t lanes, uint32_t bytes_per_lane, bool now) const {
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            if (t2_order_decided.exchange(true)) return;
+            if (!t2_order_applies() || !sample || lanes < 32) return;
+        }
+        std::vector<uint8_t> copy(sample, sample + (size_t)lanes * bytes_per_lane);
+        if (now) run_t2_order(std::move(copy), lanes, bytes_per_lane);
+        else t2_order_thread = std::thread([this, lanes, bytes_per_lane](std::vector<uint8_t> v) { run_t2_order(std::move(v), lanes, bytes_per_lane); }, std::move(copy));
+    }
+    dev::Dfa2Device dfa2_device(const DeviceTables *t) const { std::lock_guard<std::mutex> lock(mu); return t->dfa2; }
     int engine = 0;
     bool line_wide = false;      // DFA engine: byte-indexed rows (<= kWideMaxStates states) or class-indexed rows
     bool line_global = false;    // DFA engine: class-indexed table too large for LDS, kept in global memory
@@ -187,6 +249,8 @@ struct rrx_regex {
     }
 
     ~rrx_regex() {
+        if (t2_order_thread.joinable()) t2_order_thread.join();
+        for (auto &kv : t2_extra_blobs) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second); }
         for (auto &kv : scratch) if (kv.second.p) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.p); }
         for (auto &kv : onepass_scratch) {
             (void)hipSetDevice(kv.first);
@@ -443,28 +507,11 @@ struct rrx_regex {
             oT = put(T.data(), T.size() * 4);
             oL = put(lcls, 256);
             if (has_dfa2) {
-                // stride-2 tables: T2 rows of `s2` entries (odd), R interleaved copies, P = swizzled pair -> column offset
-                const uint32_t D2 = dfa2.nstates, C2 = dfa2.ncols;
-                uint32_t s2 = C2 | 1u;
-                uint32_t rep2 = 0;
-                while (rep2 < 5 && (size_t)D2 * s2 * 4 * (2u << rep2) <= dev::kDfa2TableBudget && (size_t)C2 * 4 * (2u << rep2) <= 65535) rep2++;
-                const uint32_t R2 = 1u << rep2;
-                std::vector<uint32_t> T2((size_t)D2 * s2 * R2, 0);
-                const bool ordered = t2_row_slot.size() == D2 && t2_col_slot.size() == C2 && t2_row_slot[0] == 0;
-                auto row_slot = [&](uint32_t st) { return ordered ? t2_row_slot[st] : st; };
-                auto col_slot = [&](uint32_t col) { return ordered ? t2_col_slot[col] : col; };
-                for (uint32_t st = 0; st < D2; st++)
-                    for (uint32_t col = 0; col < C2; col++) {
-                        const uint32_t v = dfa2.next2[(size_t)st * C2 + col];
-                        const uint32_t row_off = row_slot(v & 0xffffu) * s2 * 4 * R2;
-                        for (uint32_t k = 0; k < R2; k++) T2[((size_t)row_slot(st) * s2 + col_slot(col)) * R2 + k] = (row_off + 4 * k) | (v & 0xffff0000u);
-                    }
-                std::vector<uint16_t> P(128 * dev::kDfa2PStride, 0);
-                for (unsigned c1 = 0; c1 < 128; c1++)
-                    for (unsigned c2 = 0; c2 < 128; c2++) P[c1 * dev::kDfa2PStride + c2] = (uint16_t)(col_slot(dfa2.pair_col[c1 * 128 + c2]) * 4 * R2);
+                std::vector<uint32_t> T2;
+                std::vector<uint16_t> P;
+                build_dfa2_arrays(T2, P, t.dfa2);
                 oP2 = put(P.data(), P.size() * 2);
                 oT2 = put(T2.data(), T2.size() * 4);
-                t.dfa2.nrows = D2; t.dfa2.stride = s2 * R2; t.dfa2.start_off = row_slot(dfa2.start) * s2 * 4 * R2; t.dfa2.rep_log2 = rep2;
             }
             t.line.nrows = D; t.line.stride = stride * R; t.line.start_off = dfa.start * row_bytes * R; t.line.wide = wide ? 1 : 0;
             t.line.rep_log2 = rep;
@@ -623,10 +670,9 @@ int rrx_order_table(rrx_regex *re, const void *sample, uint32_t lanes, uint32_t 
     if (!re || !sample || lanes < 32 || bytes_per_lane < 2) return fail(RRX_ERR_ARG, "sample: at least 32 lanes of 2 bytes");
     {
         std::lock_guard<std::mutex> lock(re->mu);
-        if (!re->on_device.empty()) return fail(RRX_ERR_ARG, "the tables are already on a device: order the table before the first match");
         if (re->t2_order_decided) return fail(RRX_ERR_ARG, "the table order has been decided already");
     }
-    re->decide_t2_order(static_cast<const uint8_t *>(sample), lanes, bytes_per_lane);
+    re->decide_t2_order(static_cast<const uint8_t *>(sample), lanes, bytes_per_lane, /*now=*/true);
     return RRX_OK;
 }
 int rrx_table_order(const rrx_regex *re, double *conflict_before, double *conflict_after) {
@@ -634,7 +680,8 @@ int rrx_table_order(const rrx_regex *re, double *conflict_before, double *confli
     const bool profiled = re->t2_row_slot.size() == re->dfa2.nstates && re->has_dfa2 && re->t2_order_stats.half_waves;
     if (conflict_before) *conflict_before = profiled ? re->t2_order_stats.before : 0.0;
     if (conflict_after) *conflict_after = profiled ? re->t2_order_stats.after : 0.0;
-    return profiled ? 1 : 0;
+    if (profiled) return 1;
+    return re->t2_order_decided && !re->t2_order_done && re->t2_order_thread.joinable() ? 2 : 0;      // 2: the search is running
 }
 uint32_t rrx_byte_classes(const rrx_regex *re) { return re->trimmed.ncls; }
 uint32_t rrx_words_per_set(const rrx_regex *re) { return re->has_nfa ? re->nfa.W : re->has_wave ? re->nfa_wave.W : re->has_block ? re->nfa_block.W : 0; }
@@ -774,7 +821,7 @@ size_t rrx_corpus_bitmap_words(const rrx_corpus *c) { return (c->nlines + 31) / 
 
 int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accept_bits, void *stream) {
     if (!re || !c || (c->nlines && !d_accept_bits)) return fail(RRX_ERR_ARG, "null argument");
-    if (!re->t2_order_decided && c->h_sample && !c->has_high) re->decide_t2_order(c->h_sample, c->sample_lanes, kSampleBytes);
+    if (!re->t2_order_decided && c->h_sample && !c->has_high) re->decide_t2_order(c->h_sample, c->sample_lanes, kSampleBytes, /*now=*/false);
     const DeviceTables *t;
     int rc = re->tables(c->device, &t);
     if (rc) return rc;
@@ -791,7 +838,7 @@ int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accep
             : re->engine == RRX_ENGINE_NFA
                 ? dev::match_stripes_nfa(t->nfa, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream)
             : (re->has_dfa2 && !c->has_high)
-                ? dev::match_stripes_dfa2(t->dfa2, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream)
+                ? dev::match_stripes_dfa2(re->dfa2_device(t), c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream)
                 : dev::match_stripes_dfa(t->line, c->has_high, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream);
     if (e) return hip_fail((hipError_t)e, "match_stripes launch");
     return RRX_OK;
@@ -843,7 +890,7 @@ int rrx_match_device(const rrx_regex *re, int device, const void *d_bytes, size_
     if (rc) return rc;
     if (cap_words) HIP_TRY(hipMemsetAsync(d_accept_bits, 0, cap_words * sizeof(uint32_t), st));
     int e = re->engine == RRX_ENGINE_NFA ? dev::match_onepass_nfa(t->nfa, bytes, nbytes, stripe, nstripes, d_counts, d_slabs, stream)
-            : re->has_dfa2               ? dev::match_onepass_dfa2(t->dfa2, bytes, nbytes, stripe, nstripes, d_counts, d_slabs, stream)
+            : re->has_dfa2               ? dev::match_onepass_dfa2(re->dfa2_device(t), bytes, nbytes, stripe, nstripes, d_counts, d_slabs, stream)
                                          : dev::match_onepass_dfa(t->line, bytes, nbytes, stripe, nstripes, d_counts, d_slabs, stream);
     if (!e) e = dev::scan_counts(d_counts, d_base, d_base + nstripes + 1, nstripes, stream);
     // (words beyond the caller's bitmap are dropped by the compaction; whether there were any follows from the line count)

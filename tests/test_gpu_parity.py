@@ -358,22 +358,30 @@ def test_full_size_kwlog_config_properties():
 
 
 def test_profiled_table_order_changes_no_result():
-    """At its first match against a corpus of 64 MiB or more the stride-2 table is ordered by a sample of the text (rows and
-    columns permuted so that fewer lookups of a half-wave share an LDS bank).  The order must change no result: bit-identical
-    to the byte-stride table engine (which has no such order) and to the oracle on sampled chunks; the sample's conflict
-    figure must not get worse; a regex that met a small corpus first keeps the numbered order."""
+    """At its first match against a corpus of 64 MiB or more a background thread orders the stride-2 table by a sample of the
+    text (rows and columns permuted so that fewer lookups of a half-wave share an LDS bank) and swaps the tables in when it is
+    done.  Matches before, during and after the swap must give the same bits: bit-identical to the byte-stride table engine
+    (which has no such order) and to the oracle on sampled chunks; the sample's conflict figure must not get worse; a regex
+    whose table is small enough to be replicated is left alone."""
+    import time
     import synth
     n = 96 << 20
     host = synth.corpus("url", 21, n)
     dev = torch.from_numpy(host).cuda()
     corpus = rr.Corpus(dev)
+    ref = rr.RRegex(U2, rr.ENGINE_DFA).match_corpus_bits(corpus).clone()
     r = rr.RRegex(U2)
     assert r.engine_name == "dfa-stride2-table" and r.table_order is None
-    bits = r.match_corpus_bits(corpus).clone()
+    out = torch.empty_like(ref)
+    t0 = time.time()
+    launches = 0
+    while r.table_order is None and time.time() - t0 < 20:      # launches race the swap: every one must be right
+        assert torch.equal(r.match_corpus_bits(corpus, out=out), ref)
+        launches += 1
     order = r.table_order
-    assert order is not None and order[1] <= order[0] and order[0] > 1.0, order
-    ref = rr.RRegex(U2, rr.ENGINE_DFA).match_corpus_bits(corpus)
-    assert torch.equal(bits, ref)
+    assert order is not None and order[1] <= order[0] and order[0] > 1.0, (order, launches)
+    for _ in range(3):
+        assert torch.equal(r.match_corpus_bits(corpus, out=out), ref)
     acc = r.match_corpus(corpus).cpu().numpy()
     o = OracleRegex(U2)
     chunk = 1 << 20
@@ -382,13 +390,13 @@ def test_profiled_table_order_changes_no_result():
         first = int((host[:j * chunk] == 10).sum())
         want = o.match_lines(piece)
         assert (acc[first:first + len(want)] == want).all(), j
-    # the one-shot entry and the search share the regex and must not be disturbed by the order
+    # the one-shot entry shares the tables
     b2, nl = r.match_device_bits(dev)
-    assert nl == corpus.num_lines and torch.equal(b2, bits)
-    small = rr.RRegex(U2)
-    small.match_corpus_bits(rr.Corpus(dev[:1 << 20]))
+    assert nl == corpus.num_lines and torch.equal(b2, ref)
+    small = rr.RRegex(EMAIL)                                     # five states: replicated copies instead of an order
     small.match_corpus_bits(corpus)
-    assert small.table_order is None and torch.equal(small.match_corpus_bits(corpus), bits)
+    time.sleep(0.3)
+    assert small.table_order is None
 
 
 def test_nul_bytes_in_a_seven_bit_corpus_reach_the_stride2_kernel():
