@@ -36,14 +36,14 @@ struct WaveNfa {
                                            //   no class lookup, no address arithmetic on the VALU
     const uint32_t *__restrict__ xoff, *__restrict__ xtgt;
     uint32_t *acc;                         // LDS [64][WL]: this wave's exception accumulator (all zero between steps)
-    bool any_exc;
+    uint32_t any_exc;                      // (a uniform word, not a bool member: the test per byte stays scalar)
     int lane;
-    uint32_t lane_off;                     // lane * WL: this lane's words inside a row
+    uint32_t lane_byte_off;                // lane * WL * 4: this lane's words inside a row
 
     static size_t lds_bytes(const WaveNfaDevice &) { return (size_t)(kWaveThreads / 64) * 64 * WL * 4; }
     __device__ void load(const WaveNfaDevice &p, uint8_t *lds) {
         lane = threadIdx.x & 63;
-        lane_off = (uint32_t)lane * WL;
+        lane_byte_off = (uint32_t)lane * WL * 4u;
         const int wave = threadIdx.x >> 6;
         uint32_t *a = reinterpret_cast<uint32_t *>(lds);
         for (int i = threadIdx.x; i < (kWaveThreads / 64) * 64 * WL; i += kWaveThreads) a[i] = 0;
@@ -55,7 +55,7 @@ struct WaveNfa {
             self[i] = p.masks[(1 * 64 + lane) * WL + i];
             exc[i] = p.masks[(2 * 64 + lane) * WL + i];
         }
-        xoff = p.xoff; xtgt = p.xtgt; any_exc = p.exc_words != 0;
+        xoff = p.xoff; xtgt = p.xtgt; any_exc = (uint32_t)__builtin_amdgcn_readfirstlane((int)p.exc_words);
     }
     __device__ __forceinline__ bool accepting(const uint32_t (&s)[WL]) const {
         uint32_t a = 0;
@@ -72,10 +72,12 @@ struct WaveNfa {
     // The B row of a byte value (the same byte in every lane): a scalar base + this lane's 32-bit offset - global_load ... saddr
     struct Row { uint32_t b[WL]; };
     __device__ __forceinline__ Row fetch(uint32_t c) const {
-        const uint32_t *rp = rows + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)c) * (64u * WL);
+        // (scalar 64-bit base + this lane's 32-bit byte offset: the form global_load takes with an SGPR base, no VALU add)
+        const char *rb = reinterpret_cast<const char *>(rows) + (size_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)c) * (256u * WL);
+        const uint32_t *rp = reinterpret_cast<const uint32_t *>(rb + lane_byte_off);
         Row r;
 #pragma unroll
-        for (int i = 0; i < WL; i++) r.b[i] = rp[lane_off + i];
+        for (int i = 0; i < WL; i++) r.b[i] = rp[i];
         return r;
     }
     __device__ __forceinline__ void advance(uint32_t (&s)[WL], uint32_t c) const { step(s, fetch(c)); }
