@@ -399,6 +399,53 @@ def test_profiled_table_order_changes_no_result():
     assert small.table_order is None
 
 
+def test_table_order_from_a_caller_sample_after_the_tables_are_up():
+    """rrx_order_table on a regex whose tables are already on the device (it matched a small corpus first): the stride-2 arrays
+    are uploaded again in the new order and swapped in; results before and after are the oracle's."""
+    import synth
+    host = synth.corpus("url", 23, 8 << 20)
+    want = OracleRegex(U2).match_lines(host[:1 << 20])
+    dev = torch.from_numpy(host).cuda()
+    corpus = rr.Corpus(dev)
+    r = rr.RRegex(U2)
+    before = r.match_corpus(corpus).cpu().numpy()
+    assert r.table_order is None and (before[:len(want)] == want).all()
+    sample = np.ascontiguousarray(host[:256 * 4096].reshape(256, 4096)[:, :256])
+    b, a = r.order_table(sample, 256, 256)
+    assert a < b
+    after = r.match_corpus(corpus).cpu().numpy()
+    assert (after == before).all()
+    bits, nl = r.match_device_bits(dev)
+    assert nl == corpus.num_lines and (_bits_to_bytes(bits, nl) == before).all()
+
+
+def test_explicit_items_on_two_streams_share_the_scratch_in_order():
+    """rrx_match_extents is asynchronous; the item index of a large batch lives in a scratch buffer of the regex handle that
+    two streams use in turn, ordered on the device by an event.  Two different batches alternating on two streams, many
+    times, without any host synchronisation in between: every result must be its own batch's."""
+    import synth
+    r = rr.RRegex(EMAIL)
+    batches = []
+    for seed in (31, 32):
+        host = synth.corpus("email", seed, 24 << 20)
+        dev = torch.from_numpy(host).cuda()
+        nl = torch.nonzero(dev == 10).flatten()
+        off = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), nl + 1]).contiguous()
+        want = r.match_corpus(rr.Corpus(dev))[:off.numel() - 1].clone()
+        batches.append((dev, off, want))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [[torch.empty(b[1].numel() - 1, dtype=torch.uint8, device="cuda") for _ in range(6)] for b in batches]
+    for it in range(6):
+        for k in (0, 1):
+            dev, off, _ = batches[k]
+            r.match_extents(dev, off, trim=1, out=outs[k][it], stream=streams[k])
+    torch.cuda.synchronize()
+    for k in (0, 1):
+        for it in range(6):
+            assert torch.equal(outs[k][it].bool(), batches[k][2].bool()), (k, it)
+
+
 def test_nul_bytes_in_a_seven_bit_corpus_reach_the_stride2_kernel():
     """A corpus with 0x00 bytes but no byte >= 0x80 keeps the stride-2 engine (has_high stays false): its pair table row
     and column 0 must send the line to the dead state.  All table engines and the NFA, every stripe size."""
