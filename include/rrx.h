@@ -136,7 +136,8 @@ int rrx_search_all(const rrx_regex *re, const rrx_corpus *corpus, uint64_t *d_fi
 /* explicit extents: item i = d_bytes[d_off[i] .. d_off[i+1] - trim); '\n' is an ordinary character here.  Asynchronous on
  * `stream` (nothing is read back).  Large batches on a table engine (>= 65536 items) build an item index in a scratch buffer
  * the regex handle keeps until rrx_free (1 bit per byte of what is left of the allocation behind d_bytes, + 8 bytes per
- * stripe); calls with one regex on different streams are ordered on the device by an event, not on the host.        */
+ * stripe; an allocation with more than 8 GiB left behind d_bytes is not trusted as a bound: the batch extent is read back,
+ * one synchronisation); calls with one regex on different streams are ordered on the device by an event, not on the host. */
 int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, const uint64_t *d_off, size_t nitems,
                       uint32_t trim, uint8_t *d_accept, void *stream);
 

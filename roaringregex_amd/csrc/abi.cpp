@@ -1128,6 +1128,15 @@ int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, cons
             bound = (size_t)(static_cast<const uint8_t *>(abase) + asize - b);
         else (void)hipGetLastError();
     }
+    // (an allocation far larger than any batch - a memory pool - would size the index for all of it: beyond 8 GiB left behind
+    // d_bytes the batch's real extent is read back instead, one synchronisation, as round 2 did for every batch)
+    if (items && bound > ((size_t)8 << 30)) {
+        uint64_t first = 0, last = 0;
+        HIP_TRY(hipMemcpyAsync(&first, d_off, sizeof first, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        HIP_TRY(hipMemcpyAsync(&last, d_off + nitems, sizeof last, hipMemcpyDeviceToHost, (hipStream_t)stream));
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+        bound = last > first ? (size_t)last : 0;                  // (the kernels still take the extent from the offsets)
+    }
     if (items && bound >= kItemsStripesMinBytes) {
         hipStream_t st = (hipStream_t)stream;
         std::lock_guard<std::mutex> lock(re->onepass_mu);

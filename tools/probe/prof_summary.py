@@ -17,7 +17,7 @@ for d in ('pmc_sq', 'pmc_sq2', 'pmc_fetch', 'pmc_write'):
             a[0] += 1; a[1] += float(row.get('Counter_Value', 0))
         lines.append('== counters (%s): mean per dispatch' % d)
         for (kn, cn), (n, s) in sorted(agg.items()):
-            if "match_" in kn or "count_newlines" in kn:
+            if "match_" in kn or "count_newlines" in kn or "search_" in kn:
                 lines.append('  %-70s %-24s n=%d mean=%.6g' % (kn, cn, n, s / n))
 txt = '\n'.join(lines)
 open(os.path.join(out, 'summary.txt'), 'w').write(txt + '\n')
