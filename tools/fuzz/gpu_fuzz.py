@@ -142,8 +142,8 @@ while done < npat:
             wl = o.accepts(t.tobytes())
             td = torch.from_numpy(t.copy()).cuda()
             for r_ in engines:
-                if r_.engine_name.startswith("nfa-group") or r_.engine_name.startswith("nfa-block"):
-                    continue                               # (a lane group / a workgroup per string: minutes on long strings)
+                if r_.engine_name.startswith("nfa-group"):
+                    continue                               # (a lane group per string: minutes on long strings; the wave engines do run)
                 if r_.match_string(td) != wl:
                     print("MISMATCH long string", repr(p), r_.engine_name, len(t), "want", wl, flush=True)
                     sys.exit(1)
