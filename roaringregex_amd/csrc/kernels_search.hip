@@ -38,27 +38,31 @@ typedef const __attribute__((address_space(3))) uint16_t *lds_u16_ptr;
 
 struct SearchLds {
     const uint8_t *T;                           // forward line table, byte-addressed
-    const uint16_t *rev;                        // [nr][K], bit 15 = the state it leads to is accepting
     const uint16_t *cls4;                       // [256] byte -> 4 * column of the forward table ('\n' -> its own column)
-    const uint8_t *cls;                         // [256] byte -> class (reverse table)
-    uint32_t K, start_r, start_off, skip_off;
+    // reverse table, as the kernel lays it out in LDS: entry = byte offset of the next state's row | 1 if that state is
+    // accepting (rows are 2 * K bytes: even); row 0 = dead (every entry leads back to it); cls2 = byte -> 2 * class
+    uint32_t rev_base, cls2_base;               // LDS addresses
+    uint32_t start_row;                         // row offset of the reverse start state
+    uint32_t start_off, skip_off;
 };
+typedef const __attribute__((address_space(3))) uint8_t *lds_u8_ptr;
 
+// one reverse step: r = row offset | accept bit of the state reached so far, c = the byte in front
+__device__ __forceinline__ uint32_t reverse_step(const SearchLds &t, uint32_t r, uint32_t cb) {
+    return *reinterpret_cast<lds_u16_ptr>((r & 0xfffeu) + cb + t.rev_base);
+}
 // first byte position s in [lo, e] such that bytes[s, e) is accepted (e itself if only the empty string is: cannot
-// happen here, patterns that accept the empty string take another path)
+// happen here, patterns that accept the empty string take another path).  The plain form: a byte per turn (a lane whose
+// job queue is full and cannot wait for the wave's common walk - rare since the queue is drained whenever a lane's fills up)
 __device__ __forceinline__ size_t reverse_walk(const SearchLds &t, const uint8_t *__restrict__ bytes, size_t lo, size_t e) {
-    uint32_t r = t.start_r;
+    uint32_t r = t.start_row;
     size_t best = e, k = e;
-    uint32_t w = 0;
-    bool have = false;
     while (k > lo) {
         k--;
-        if (!have || (k & 3) == 3) { w = *reinterpret_cast<const uint32_t *>(bytes + (k & ~(size_t)3)); have = true; }
-        const uint32_t c = (w >> (8 * (k & 3))) & 0xffu;
-        const uint32_t x = t.rev[r * t.K + t.cls[c]];
-        r = x & 0x7fffu;
-        if (!r) break;                                            // state 0 is dead
-        if (x & 0x8000u) best = k;
+        const uint32_t cb = *reinterpret_cast<lds_u8_ptr>(t.cls2_base + (uint32_t)bytes[k]);
+        r = reverse_step(t, r, cb);
+        if (r == 0u) break;                                       // row 0 is dead (and not accepting)
+        if (r & 1u) best = k;
     }
     return best;
 }
@@ -146,14 +150,21 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
                                                                   // LDS in this kernel; the launcher checks it on the host)
     const uint32_t *Tsrc = MODE == kFirst ? prog.T : prog.T_all;
     for (uint32_t i = threadIdx.x; i < t_words; i += blockDim.x) T[i] = Tsrc[i] + t_base;
-    for (uint32_t i = threadIdx.x; i < rev_words; i += blockDim.x) R[i] = reinterpret_cast<const uint32_t *>(prog.rev)[i];
+    // the reverse table changes form on the way in: next state | accepting << 15  ->  row offset | accepting (see SearchLds);
+    // the byte -> class map is doubled (classes are < 128)
+    const uint32_t rev_row = 2u * prog.ncls;
+    for (uint32_t i = threadIdx.x; i < rev_words; i += blockDim.x) {
+        const uint32_t w = reinterpret_cast<const uint32_t *>(prog.rev)[i];
+        const uint32_t a = (w & 0x7fffu) * rev_row | ((w >> 15) & 1u), b = ((w >> 16) & 0x7fffu) * rev_row | (w >> 31);
+        R[i] = a | b << 16;
+    }
     for (uint32_t i = threadIdx.x; i < 128; i += blockDim.x) C4[i] = reinterpret_cast<const uint32_t *>(prog.cls4)[i];
-    for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x) C[i] = reinterpret_cast<const uint32_t *>(prog.cls)[i];
+    for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x) C[i] = (reinterpret_cast<const uint32_t *>(prog.cls)[i] << 1) & 0xfefefefeu;
     for (uint32_t i = threadIdx.x; i < kSearchWaves * kArrays * kStageLines; i += blockDim.x) stage[i] = kStageInit;
     __syncthreads();
     SearchLds t;
-    t.T = smem; t.rev = reinterpret_cast<const uint16_t *>(R); t.cls4 = reinterpret_cast<const uint16_t *>(C4);
-    t.cls = reinterpret_cast<const uint8_t *>(C); t.K = prog.ncls; t.start_r = prog.start_r;
+    t.T = smem; t.cls4 = reinterpret_cast<const uint16_t *>(C4);
+    t.rev_base = t_base + 4u * t_words; t.cls2_base = t.rev_base + 4u * rev_words; t.start_row = prog.start_r * rev_row;
     t.start_off = prog.start_off + t_base; t.skip_off = prog.skip_off + t_base;
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -347,41 +358,55 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
         decided = false;
         if constexpr (MODE == kAll && !COUNTING) { if (owned) set_first(ord, lane_base + emitted); }
     };
-    // ---- walks back: every lane that has a queued job takes its oldest one; then ONE tight loop steps all of them (a
-    // reverse step per turn: text re-read from L1/L2 four bytes per load, the next word requested a word ahead) until the
+    // ---- walks back: every lane that has a queued job takes its oldest one; then ONE tight loop steps all of them until the
     // longest is done; then the lanes emit.  (The first version ran pop, step and emit in one loop body, each under its own
-    // lane mask - every turn paid for all three, 80 instructions for one reverse step - and a lane whose queue was full
-    // walked alone inside the event loop: 56 % of the first-match search on the email config.)  Positions are offsets
-    // from the chunk start.
+    // lane mask - every turn paid for all three, 80 instructions for one reverse step.)  A turn of the loop takes the FOUR
+    // bytes below the walk's position: the text is re-read from L1/L2 as aligned words, a word requested a turn ahead, and
+    // put together with v_alignbyte (the walk starts anywhere in a word); the four class lookups are issued before the four
+    // dependent row lookups; the byte selects are static.  A lane that has died or passed its lower bound keeps stepping to
+    // the end of the turn: row 0 leads to row 0, and a start below the bound is never taken.  Round 3: 8 VALU + 2 LDS per
+    // reverse step (round 2: a byte per turn, a ballot and a branch per byte, 22 VALU per byte of text on the email config).
+    // Positions are offsets from the chunk start.  until_room: stop as soon as no lane's queue is full (called from the
+    // event loop, so that no lane ever walks alone); otherwise until every queue is empty.
     const uint8_t *const cbase = bytes + cstart;
-    auto drain = [&]() {
-        while (__ballot(njobs != 0)) {
+    auto text_word = [&](uint32_t at) -> uint32_t { return *reinterpret_cast<const uint32_t *>(cbase + at); };   // at: multiple of 4
+    auto drain = [&](bool until_room) {
+        while (until_room ? __ballot(njobs == (uint32_t)kJobs) : __ballot(njobs != 0)) {
             const bool have = njobs != 0;
-            uint32_t lo = 0, e_rel = 0, cur_at = 0, cur_ls = 0, k = 0, best = 0, r = 0, w = 0, wn = 0;
+            uint32_t lo = 0, e_rel = 0, cur_at = 0, cur_ls = 0, kb = 0, best = 0, r = 0, hi_w = 0, lo_w = 0, sh = 0;
             if (have) {
                 lo = job_lo[0]; e_rel = job_e[0]; cur_at = job_at[0]; cur_ls = job_ls[0];
 #pragma unroll
                 for (int j = 0; j + 1 < kJobs; j++) { job_lo[j] = job_lo[j + 1]; job_e[j] = job_e[j + 1]; job_at[j] = job_at[j + 1]; job_ls[j] = job_ls[j + 1]; }
                 njobs--;
-                k = e_rel; best = e_rel; r = t.start_r;
-                const uint32_t a0 = (k - 1u) & ~3u;               // e_rel > lo: a match is never empty here
-                wn = *reinterpret_cast<const uint32_t *>(cbase + a0);
-                w = wn;
-                if (a0 >= 4u && a0 > lo) wn = *reinterpret_cast<const uint32_t *>(cbase + a0 - 4u);
+                kb = e_rel; best = e_rel; r = t.start_row;      // e_rel > lo: a match is never empty here
+                sh = kb & 3u;
+                const uint32_t a1 = kb & ~3u;                     // the word that holds byte kb: its low `sh` bytes are wanted
+                if (sh) hi_w = text_word(a1);
+                if (a1 >= 4u) lo_w = text_word(a1 - 4u);          // (a1 < 4: sh > 0 and lo = 0 - the wanted bytes are all in hi_w)
             }
             bool active = have;
             while (__ballot(active)) {
                 if (active) {
-                    k--;
-                    const uint32_t c = (w >> (8u * (k & 3u))) & 0xffu;
-                    const uint32_t x = t.rev[r * t.K + t.cls[c]];
-                    r = x & 0x7fffu;
-                    if (r && (x & 0x8000u)) best = k;
-                    if (!r || k == lo) active = false;            // dead, or at the lower bound: done
-                    else if ((k & 3u) == 0) {                     // the next byte down lies in the word below
-                        w = wn;
-                        if (k >= 8u && k - 4u > lo) wn = *reinterpret_cast<const uint32_t *>(cbase + k - 8u);
-                    }
+                    // bytes kb-4 .. kb-1 = ({hi_w, lo_w} >> 8 sh): byte 3 of w is the nearest
+                    const uint32_t w = __builtin_amdgcn_alignbyte(hi_w, lo_w, sh);
+                    hi_w = lo_w;
+                    const uint32_t below = (kb & ~3u) - 8u;       // requested now, used next turn
+                    if (kb >= 8u) lo_w = text_word(below);
+                    uint32_t a3, a2, a1_, a0;
+                    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(a3) : "v"(t.cls2_base), "v"(w));
+                    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(a2) : "v"(t.cls2_base), "v"(w));
+                    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(a1_) : "v"(t.cls2_base), "v"(w));
+                    asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(a0) : "v"(t.cls2_base), "v"(w));
+                    const uint32_t c3 = *reinterpret_cast<lds_u8_ptr>(a3), c2 = *reinterpret_cast<lds_u8_ptr>(a2);
+                    const uint32_t c1 = *reinterpret_cast<lds_u8_ptr>(a1_), c0 = *reinterpret_cast<lds_u8_ptr>(a0);
+                    const uint32_t room = kb - lo;                // steps this walk may still take (>= 1)
+                    r = reverse_step(t, r, c3); if ((r & 1u) && room > 0u) best = kb - 1u;
+                    r = reverse_step(t, r, c2); if ((r & 1u) && room > 1u) best = kb - 2u;
+                    r = reverse_step(t, r, c1); if ((r & 1u) && room > 2u) best = kb - 3u;
+                    r = reverse_step(t, r, c0); if ((r & 1u) && room > 3u) best = kb - 4u;
+                    active = r != 0u && room > 4u;                // row 0: dead
+                    kb -= 4u;                                     // (only read again while active: then kb > lo >= 0)
                 }
             }
             if (have) emit(cur_at, best - cur_ls, e_rel - cur_ls);
@@ -401,6 +426,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     for (int i = 0; i < kEv; i++) {
         uint32_t m = ev[i];
         while (m) {
+            if constexpr (kWalks) { if (__ballot(njobs == (uint32_t)kJobs)) drain(true); }      // nobody walks alone
             const int z = __clz((int)m) >> 1;                     // byte of the word, 0 = first
             const uint32_t f = (m >> (30 - 2 * z)) & 3u;
             m &= ~(3u << (30 - 2 * z));
@@ -421,6 +447,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
         on_hit(pos, f);
     };
     if constexpr (MODE == kAll && !COUNTING) {
+        if (__ballot(phase == 1 && nfh <= (uint32_t)kFollowHits && njobs + nfh > (uint32_t)kJobs)) drain(false);      // room for them
         if (phase == 1 && nfh <= (uint32_t)kFollowHits) {         // the counting pass has been there: its hits, in order
 #pragma unroll
             for (int j = 0; j < kFollowHits; j++)
@@ -476,7 +503,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
             }
         }
         // ---- 4c. the queued walks
-        if constexpr (kWalks) drain();
+        if constexpr (kWalks) drain(false);
     }
     // my last line, open to the end of the data (or ended by its '\n' beyond my bytes)
     if constexpr (MODE == kFirst) { if (owned && !decided && ord >= kStageLines) emit(ord, kNone, kNone); }
@@ -544,6 +571,7 @@ static size_t search_table_bytes(const SearchChunkDevice &p) { return ((size_t)p
 static uint32_t search_stage_lines(const SearchChunkDevice &p, int mode) {
     const size_t tb = search_table_bytes(p), per = (size_t)kSearchWaves * 4 * ((mode == kFill || mode == kAll) ? 2 : 1);
     if (tb + per * 128 > kSearchChunkLdsBudget) return 0;
+    if ((size_t)p.nr * p.ncls * 2 > 65534 || p.ncls > 128) return 0;      // reverse rows are addressed by 16-bit byte offsets, classes doubled in a byte
     size_t n = (kSearchChunkLdsBudget - tb) / per;
     n = n / 64 * 64;
     return (uint32_t)(n > kMaxStageLines ? kMaxStageLines : n);
