@@ -200,7 +200,7 @@ struct SearchChunkDevice {
     const uint16_t *rev = nullptr;               // [nr][ncls] reverse table, bit 15 = leads to an accepting state
     const uint8_t *cls = nullptr;                // [256] byte -> class
 };
-constexpr size_t kSearchChunkLdsBudget = 80 * 1024;      // two workgroups per CU
+constexpr size_t kSearchChunkLdsBudget = 160 * 1024;     // one workgroup of 16 waves per CU: the whole LDS
 size_t search_chunk_bytes();                             // bytes of text per wave (the granularity of its newline index)
 size_t search_chunks_lds_bytes(const SearchChunkDevice &p);
 // chunk_base: per-chunk newline prefix in the stripe_base format (bit 63: the chunk begins at the start of a line)

@@ -25,12 +25,14 @@ namespace rrx {
 namespace dev {
 namespace {
 
-constexpr int kSearchWaves = 8;                 // waves per workgroup (one table copy in LDS serves them)
+constexpr int kSearchWaves = 16;                // waves per workgroup: ONE workgroup per CU (128 VGPRs: four waves per SIMD), one table copy in LDS serves them
 constexpr int kSearchS = 256;                   // bytes per lane: two 128-byte rounds (the per-lane costs that do not scale with
                                                 // the bytes - following the last line, numbering, write-out - are paid half as often)
 constexpr uint32_t kSearchChunk = 64 * kSearchS;
 constexpr uint32_t kMaxStageLines = 2048;       // staged lines per wave (what the tables leave of the LDS budget, at most this); lines beyond go to memory directly
 constexpr uint32_t kNone = 0xffffffffu;
+constexpr uint32_t kPool = 128;                 // walk jobs a wave collects before it walks 64 of them, a job per lane (four words each)
+constexpr uint32_t kPoolWords = kPool * 4;
 constexpr uint32_t kDirect = 0xfffffffeu;       // staged entry: the result did not fit 16 + 16 bits and went to memory directly
 
 typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
@@ -143,7 +145,8 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     uint32_t *T = C4 + 128;
     uint32_t *R = T + t_words;
     uint32_t *C = R + rev_words;                                  // 64 words
-    uint32_t *stage = C + 64;                                     // [wave][kArrays][kStageLines]
+    uint32_t *pool_all = C + 64;                                  // [wave][kPoolWords]: the waves' walk jobs
+    uint32_t *stage = pool_all + kSearchWaves * kPoolWords;       // [wave][kArrays][kStageLines]
     constexpr uint32_t kArrays = (MODE == kFill || MODE == kAll) ? 2 : 1;     // results packed start | end << 16 (kCount: the count); kFill / kAll: + slot bases
     constexpr uint32_t kStageInit = MODE == kCount ? 0u : kNone;  // a line without a match: "none" / zero matches
     const uint32_t t_base = 512u;                                 // LDS address of T: the dynamic LDS starts at address 0 (no static
@@ -170,6 +173,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t *st_s = stage + (size_t)wave * kArrays * kStageLines;
     uint32_t *st_f = st_s + kStageLines;                          // kFill / kAll: first[line] - first[the wave's first line]
+    uint32_t *const pool = pool_all + (size_t)wave * kPoolWords;
     auto next_chunk = [&](size_t prev, bool start) -> size_t {
         if constexpr (MODE == kAll) {                             // by ticket (see SearchAllArgs)
             uint32_t tk = 0;
@@ -321,15 +325,13 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     auto run_pass = [&](auto counting_tag) {
     constexpr bool COUNTING = decltype(counting_tag)::value;
     e = e_fwd; ord = ord0; emitted = 0;
-    constexpr int kJobs = 4;
-    uint32_t job_lo[kJobs], job_e[kJobs], job_at[kJobs], job_ls[kJobs];       // slot 0 is the next to run
-    uint32_t njobs = 0;
     bool owned = fresh, decided = false;                          // the current line: is it mine; kFirst: has its match been found
     if constexpr (MODE == kAll && !COUNTING) { if (fresh) set_first(ord0, lane_base); }
     const uint32_t my_rel = (uint32_t)(my - cstart), my_end_rel = (uint32_t)(my_end - cstart);
     uint32_t ls = my_rel;                                         // its first byte (valid if owned)
     uint32_t lb = my_rel;                                         // kFill: a match may not start before here (the previous match's end)
     uint32_t cnt = 0;                                             // kCount / kFill: matches of the current line so far
+    uint32_t next_slot = kPool;                                   // where my next job goes in the pool (set by the caller of on_hit, wave-wide: see reserve)
     auto on_hit = [&](uint32_t pos, uint32_t f) {                 // the byte at `pos` completes a match
         if (!owned) return;
         if constexpr (MODE == kCount) { cnt++; return; }
@@ -337,14 +339,13 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
         const uint32_t at = MODE == kFirst ? ord : MODE == kAll ? lane_base + emitted : slot_base(ord) + cnt;
         const uint32_t lower = MODE == kFirst ? ls : lb;
         if (f == 3u) emit(at, lower - ls, pos + 1 - ls);          // accepted from the restart point itself: it starts there
-        else if (njobs < kJobs) {
-#pragma unroll
-            for (int j = 0; j < kJobs; j++)
-                if ((uint32_t)j == njobs) { job_lo[j] = lower; job_e[j] = pos + 1; job_at[j] = at; job_ls[j] = ls; }
-            njobs++;
-        } else {                                                  // (several matches inside one text word with the queue full)
-            const size_t s0 = reverse_walk(t, bytes, cstart + lower, cstart + pos + 1);
-            emit(at, (uint32_t)(s0 - cstart) - ls, pos + 1 - ls);
+        else {
+            const uint32_t idx = next_slot++;
+            if (idx < kPool) { pool[4 * idx] = lower; pool[4 * idx + 1] = pos + 1; pool[4 * idx + 2] = at; pool[4 * idx + 3] = ls; }
+            else {                                                // (no room even after a drain: more jobs in one turn than the pool holds; the last bytes of the corpus)
+                const size_t s0 = reverse_walk(t, bytes, cstart + lower, cstart + pos + 1);
+                emit(at, (uint32_t)(s0 - cstart) - ls, pos + 1 - ls);
+            }
         }
         if constexpr (MODE == kFirst) decided = true;
         else { cnt++; emitted++; lb = pos + 1; }
@@ -358,27 +359,30 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
         decided = false;
         if constexpr (MODE == kAll && !COUNTING) { if (owned) set_first(ord, lane_base + emitted); }
     };
-    // ---- walks back: every lane that has a queued job takes its oldest one; then ONE tight loop steps all of them until the
-    // longest is done; then the lanes emit.  (The first version ran pop, step and emit in one loop body, each under its own
-    // lane mask - every turn paid for all three, 80 instructions for one reverse step.)  A turn of the loop takes the FOUR
-    // bytes below the walk's position: the text is re-read from L1/L2 as aligned words, a word requested a turn ahead, and
-    // put together with v_alignbyte (the walk starts anywhere in a word); the four class lookups are issued before the four
-    // dependent row lookups; the byte selects are static.  A lane that has died or passed its lower bound keeps stepping to
-    // the end of the turn: row 0 leads to row 0, and a start below the bound is never taken.  Round 3: 8 VALU + 2 LDS per
-    // reverse step (round 2: a byte per turn, a ballot and a branch per byte, 22 VALU per byte of text on the email config).
-    // Positions are offsets from the chunk start.  until_room: stop as soon as no lane's queue is full (called from the
-    // event loop, so that no lane ever walks alone); otherwise until every queue is empty.
+    // ---- walks back.  A hit whose start is not known leaves a job (lower bound, match end, where the result goes, line
+    // start) in the wave's POOL in LDS; whenever the pool holds more than 64 the wave walks 64 of them, a job per lane, in ONE
+    // tight loop until the longest is done, then the lanes emit.  (Round 2 and the first form of round 3 kept a queue of four
+    // jobs per lane in registers: a round of walks then served one job of every lane that had any, and the number of rounds
+    // was the number of hits of the busiest lane - 12 on the email config where the mean is 6.5.)  A turn of the loop takes
+    // the FOUR bytes below the walk's position: the text is re-read from L1/L2 as aligned words, a word requested a turn
+    // ahead, and put together with v_alignbyte (the walk starts anywhere in a word); the four class lookups are issued before
+    // the four dependent row lookups; the byte selects are static.  A lane that has died or passed its lower bound keeps
+    // stepping to the end of the turn: row 0 leads to row 0, and a start below the bound is never taken.  8 VALU + 2 LDS per
+    // reverse step (round 2: a byte per turn, a ballot and a branch per byte).  Positions are offsets from the chunk start.
     const uint8_t *const cbase = bytes + cstart;
     auto text_word = [&](uint32_t at) -> uint32_t { return *reinterpret_cast<const uint32_t *>(cbase + at); };   // at: multiple of 4
-    auto drain = [&](bool until_room) {
-        while (until_room ? __ballot(njobs == (uint32_t)kJobs) : __ballot(njobs != 0)) {
-            const bool have = njobs != 0;
+    uint32_t fill = 0;                                            // jobs in the pool (wave-uniform; the pool is empty between chunks and passes)
+    // everything: every job in the pool; otherwise whole rounds of 64 only (the rest moves to the front and waits for company)
+    auto drain = [&](bool everything) {
+        const uint32_t count = fill;
+        uint32_t base = 0;
+        while (everything ? base < count : base + 64u <= count) {
+            const uint32_t jn = base + (uint32_t)lane;
+            const bool have = jn < count;
+            base += 64u;
             uint32_t lo = 0, e_rel = 0, cur_at = 0, cur_ls = 0, kb = 0, best = 0, r = 0, hi_w = 0, lo_w = 0, sh = 0;
             if (have) {
-                lo = job_lo[0]; e_rel = job_e[0]; cur_at = job_at[0]; cur_ls = job_ls[0];
-#pragma unroll
-                for (int j = 0; j + 1 < kJobs; j++) { job_lo[j] = job_lo[j + 1]; job_e[j] = job_e[j + 1]; job_at[j] = job_at[j + 1]; job_ls[j] = job_ls[j + 1]; }
-                njobs--;
+                lo = pool[4 * jn]; e_rel = pool[4 * jn + 1]; cur_at = pool[4 * jn + 2]; cur_ls = pool[4 * jn + 3];
                 kb = e_rel; best = e_rel; r = t.start_row;      // e_rel > lo: a match is never empty here
                 sh = kb & 3u;
                 const uint32_t a1 = kb & ~3u;                     // the word that holds byte kb: its low `sh` bytes are wanted
@@ -411,6 +415,38 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
             }
             if (have) emit(cur_at, best - cur_ls, e_rel - cur_ls);
         }
+        const uint32_t rem = base < count ? count - base : 0u;    // < 64
+        if (rem && base && (uint32_t)lane < rem) {
+            const uint32_t j = base + (uint32_t)lane;
+            const uint32_t v0 = pool[4 * j], v1 = pool[4 * j + 1], v2 = pool[4 * j + 2], v3 = pool[4 * j + 3];
+            pool[4 * lane] = v0; pool[4 * lane + 1] = v1; pool[4 * lane + 2] = v2; pool[4 * lane + 3] = v3;
+        }
+        fill = (uint32_t)__builtin_amdgcn_readfirstlane((int)rem);
+    };
+    // Wave-uniform, before a turn in which the lanes push n jobs between them (exactly n: every reserved slot gets its job,
+    // the pool has no holes): -> the first of their slots; slots >= kPool do not exist, those lanes walk alone.  The lanes
+    // take consecutive slots in lane order (lane_offset: jobs of the lanes below me, from per-lane counts of 0 .. 4).
+    auto reserve = [&](uint32_t n) -> uint32_t {
+        if (fill + n > kPool) { drain(false); if (fill + n > kPool) drain(true); }
+        const uint32_t first_slot = fill;
+        fill = (uint32_t)__builtin_amdgcn_readfirstlane((int)(fill + n < kPool ? fill + n : kPool));      // (wave-uniform: keep it in a scalar register)
+        return first_slot;
+    };
+    auto below = [&](uint64_t m) -> uint32_t { return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u)); };
+    auto reserve_one = [&](bool push) {                           // I am about to push a job, or not; sets next_slot
+        const uint64_t m1 = __ballot(push);
+        if (m1) { const uint32_t first_slot = reserve((uint32_t)__popcll(m1)); if (push) next_slot = first_slot + below(m1); }
+    };
+    auto reserve_for = [&](uint32_t mine) {                       // mine: 0 .. 4 jobs I am about to push; sets next_slot
+        const uint64_t m1 = __ballot(mine > 0u);
+        if (!m1) return;
+        uint32_t n = (uint32_t)__popcll(m1), off = below(m1);
+        if constexpr (MODE != kFirst) {
+            const uint64_t m2 = __ballot(mine > 1u), m3 = __ballot(mine > 2u), m4 = __ballot(mine > 3u);
+            n += (uint32_t)__popcll(m2) + (uint32_t)__popcll(m3) + (uint32_t)__popcll(m4);
+            off += below(m2) + below(m3) + below(m4);
+        }
+        next_slot = reserve(n) + off;
     };
     constexpr bool kWalks = !COUNTING && MODE != kCount;          // this pass queues jobs
     // ---- 4a. my events, word by word (a static loop over the event words, a dynamic one over the events of a word: the
@@ -422,17 +458,65 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
         for (int i = 0; i < kEv; i++) emitted += __popc(ev[i] & 0xaaaaaaaau);
         owned = fresh || nl > 0;
     } else {
+    bool fast_first = false;
+    if constexpr (MODE == kFirst) fast_first = hi_ord < (int64_t)kStageLines;      // every line of the chunk has a staged entry ("none" by default)
+    if (fast_first) {
+        // first match per line, the common case: only the HITS are visited.  The forward table leaves one hit per line (SKIP
+        // until the '\n'), every hit among my events is mine (see above), and what a hit needs of the '\n' events - its line's
+        // ordinal and first byte - are a popcount and a find-first over the '\n' fields in front of it.  (Round 2 took every
+        // event in turn, '\n' and hit alike, each a pass through the whole body: on 20-byte lines the event loop cost twice the
+        // forward pass; on 5-byte lines three quarters of the events are '\n'.)
+        uint32_t run_ord = ord0, run_ls = my_rel, last_hit_end = 0;
+#pragma unroll
+        for (int i = 0; i < kEv; i++) {
+            const uint32_t evw = ev[i];
+            const uint32_t nlm = evw & ~(evw >> 1) & 0x55555555u;     // fields equal to 1: bit 30 - 2 y for byte y
+            uint32_t hm = evw & 0xaaaaaaaau;                          // fields 2 and 3: bit 31 - 2 y
+            while (__ballot(hm != 0)) {
+                uint32_t f = 0, pos = 0;
+                if (hm) {
+                    const int zb = __clz((int)hm);                    // 2 y
+                    hm &= ~(0x80000000u >> zb);
+                    f = (evw >> (30 - zb)) & 3u;
+                    const uint32_t above = zb ? nlm & ~(0xffffffffu >> zb) : 0u;      // the '\n' of this word in front of the hit
+                    pos = my_rel + (uint32_t)(16 * i) + (uint32_t)(zb >> 1);
+                    ord = run_ord + (uint32_t)__popc(above);
+                    ls = above ? my_rel + (uint32_t)(16 * i) + ((uint32_t)(31 - __ffs((int)above)) >> 1) + 1u : run_ls;
+                    owned = true;
+                    last_hit_end = pos + 1u;
+                }
+                reserve_one(f == 2u);
+                if (f) on_hit(pos, f);
+            }
+            if (nlm) { run_ord += (uint32_t)__popc(nlm); run_ls = my_rel + (uint32_t)(16 * i) + ((uint32_t)(31 - __ffs((int)nlm)) >> 1) + 1u; }
+        }
+        ord = run_ord; ls = run_ls; lb = run_ls; cnt = 0;
+        owned = nl ? run_ls < my_end_rel : fresh;                     // a line that starts at my_end is the next lane's
+        decided = last_hit_end > run_ls;                              // my open last line has its match already
+    } else {
 #pragma unroll
     for (int i = 0; i < kEv; i++) {
         uint32_t m = ev[i];
-        while (m) {
-            if constexpr (kWalks) { if (__ballot(njobs == (uint32_t)kJobs)) drain(true); }      // nobody walks alone
-            const int z = __clz((int)m) >> 1;                     // byte of the word, 0 = first
-            const uint32_t f = (m >> (30 - 2 * z)) & 3u;
-            m &= ~(3u << (30 - 2 * z));
-            const uint32_t pos = my_rel + (uint32_t)(16 * i + z);
-            if (f == 1u) on_newline(pos); else on_hit(pos, f);
+        if constexpr (kWalks) {
+            while (__ballot(m != 0)) {                            // (a wave-uniform loop: the walks in between need every lane)
+                const uint32_t z = (uint32_t)__clz((int)m) >> 1;  // byte of the word, 0 = first (no event left: 16, f = 0)
+                const uint32_t sh = (30u - 2u * z) & 31u;
+                const uint32_t f = m ? (m >> sh) & 3u : 0u;
+                m &= ~(3u << sh);
+                const uint32_t pos = my_rel + (uint32_t)(16 * i) + z;
+                reserve_one(f == 2u && owned);
+                if (f == 1u) on_newline(pos); else if (f) on_hit(pos, f);
+            }
+        } else {
+            while (m) {
+                const int z = __clz((int)m) >> 1;
+                const uint32_t f = (m >> (30 - 2 * z)) & 3u;
+                m &= ~(3u << (30 - 2 * z));
+                const uint32_t pos = my_rel + (uint32_t)(16 * i + z);
+                if (f == 1u) on_newline(pos); else on_hit(pos, f);
+            }
         }
+    }
     }
     }
     // my last line goes on beyond my bytes and is still open (kFirst: undecided): follow it
@@ -447,7 +531,15 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
         on_hit(pos, f);
     };
     if constexpr (MODE == kAll && !COUNTING) {
-        if (__ballot(phase == 1 && nfh <= (uint32_t)kFollowHits && njobs + nfh > (uint32_t)kJobs)) drain(false);      // room for them
+        {
+            uint32_t mine = 0;                                    // the remembered hits whose start is not known
+            if (phase == 1 && nfh <= (uint32_t)kFollowHits) {
+#pragma unroll
+                for (int j = 0; j < kFollowHits; j++)
+                    if ((uint32_t)j < nfh && (fh[j] & 3u) == 2u) mine++;
+            }
+            reserve_for(mine);
+        }
         if (phase == 1 && nfh <= (uint32_t)kFollowHits) {         // the counting pass has been there: its hits, in order
 #pragma unroll
             for (int j = 0; j < kFollowHits; j++)
@@ -458,16 +550,16 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     size_t fbyte = my_end;                                        // follow position (word by word while whole 16-byte blocks lie in the data)
     uint4 cur = make_uint4(0, 0, 0, 0), nxt = cur;
     if (phase == 1 && fbyte + 16 <= nbytes) cur = *reinterpret_cast<const uint4 *>(bytes + fbyte);
-    while (phase < 2 || njobs) {
+    {
         // ---- 4b. the rest of my last line: sixteen bytes per load, the next sixteen requested before these are stepped
         // (the loop is a chain of memory round trips otherwise), stepped like the forward pass, a text word per turn
-        while (phase == 1 && njobs < kJobs) {
+        auto follow_step = [&](uint32_t &acc, uint32_t &wrel) {   // -> the events of the word stepped (2 bits per byte, byte 0 in bits 7..6)
             const size_t fpos = fbyte & ~(size_t)15;
             if (fpos + 16 <= nbytes) {
                 const uint32_t fq = (uint32_t)(fbyte & 15) >> 2;  // text word of `cur` to step
                 if (fq == 0 && fpos + 32 <= nbytes) nxt = *reinterpret_cast<const uint4 *>(bytes + fpos + 16);
                 const uint32_t w = fq == 0 ? cur.x : fq == 1 ? cur.y : fq == 2 ? cur.z : cur.w;
-                uint32_t acc = 0, a0, a1, a2, a3, c0, c1, c2, c3;
+                uint32_t a0, a1, a2, a3, c0, c1, c2, c3;
 #define RRX_SEARCH_COL(W, SEL, A, C)                                                                                              \
                 asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL : "=v"(A) : "v"(1u), "v"(W)); \
                 C = *reinterpret_cast<lds_u16_ptr>(A);
@@ -483,27 +575,51 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
                 RRX_SEARCH_STEP(c0) RRX_SEARCH_STEP(c1) RRX_SEARCH_STEP(c2) RRX_SEARCH_STEP(c3)
 #undef RRX_SEARCH_STEP
 #undef RRX_SEARCH_COL
-                const uint32_t wrel = (uint32_t)(fbyte - cstart);
-                while (acc && phase == 1) {                       // 2 bits per byte, byte 0 in bits 7..6
-                    const int z = (__clz((int)acc) - 24) >> 1;
-                    const uint32_t f = (acc >> (6 - 2 * z)) & 3u;
-                    acc &= ~(3u << (6 - 2 * z));
-                    if (f == 1u) phase = 2;                       // the line's '\n': done (what lies behind it is not mine)
-                    else { follow_hit(wrel + (uint32_t)z, f); if (MODE == kFirst) phase = 2; }
-                }
+                wrel = (uint32_t)(fbyte - cstart);
                 fbyte += 4;
                 if ((fbyte & 15) == 0) cur = nxt;
             } else {                                              // the last bytes of the corpus, one by one
-                for (; fbyte < nbytes && phase == 1 && njobs < kJobs; fbyte++) {
+                next_slot = kPool;                                // (no slots reserved here: these few hits walk alone)
+                for (; fbyte < nbytes && phase == 1; fbyte++) {
                     const uint32_t f = step(e, bytes[fbyte]);
                     if (f == 1u) phase = 2;
                     else if (f) { follow_hit((uint32_t)(fbyte - cstart), f); if (MODE == kFirst) phase = 2; }
                 }
                 if (fbyte >= nbytes) phase = 2;                   // the end of the data ends the line
             }
+        };
+        auto follow_events = [&](uint32_t acc, uint32_t wrel) {
+            while (acc && phase == 1) {
+                const int z = (__clz((int)acc) - 24) >> 1;
+                const uint32_t f = (acc >> (6 - 2 * z)) & 3u;
+                acc &= ~(3u << (6 - 2 * z));
+                if (f == 1u) phase = 2;                           // the line's '\n': done (what lies behind it is not mine)
+                else { follow_hit(wrel + (uint32_t)z, f); if (MODE == kFirst) phase = 2; }
+            }
+        };
+        if constexpr (kWalks) {
+            // wave-uniform, like the event loop: the walks in between need every lane
+            while (__ballot(phase == 1)) {
+                uint32_t acc = 0, wrel = 0;
+                if (phase == 1) follow_step(acc, wrel);
+                if (__ballot(acc != 0)) {                         // (most turns meet neither a '\n' nor a hit)
+                    // only the events up to the one that ends my following count: the line's '\n' (kFirst: or the first hit)
+                    uint32_t stop = acc & ~(acc >> 1) & 0x55u;
+                    if constexpr (MODE == kFirst) stop |= (acc >> 1) & 0x55u;
+                    if (stop) acc &= ~((1u << (31 - __clz((int)stop))) - 1u);
+                    reserve_for((uint32_t)__popc((acc >> 1) & ~acc & 0x55u));       // my hits whose start is not known (fields equal to 2)
+                    follow_events(acc, wrel);
+                }
+            }
+        } else {
+            while (phase == 1) {
+                uint32_t acc = 0, wrel = 0;
+                follow_step(acc, wrel);
+                follow_events(acc, wrel);
+            }
         }
-        // ---- 4c. the queued walks
-        if constexpr (kWalks) drain(false);
+        // ---- 4c. the walks still waiting
+        if constexpr (kWalks) drain(true);
     }
     // my last line, open to the end of the data (or ended by its '\n' beyond my bytes)
     if constexpr (MODE == kFirst) { if (owned && !decided && ord >= kStageLines) emit(ord, kNone, kNone); }
@@ -565,7 +681,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
 }  // namespace
 
 size_t search_chunk_bytes() { return kSearchChunk; }
-static size_t search_table_bytes(const SearchChunkDevice &p) { return ((size_t)p.nrows * p.stride + (p.nr * p.ncls + 1) / 2 + 128 + 64) * 4; }
+static size_t search_table_bytes(const SearchChunkDevice &p) { return ((size_t)p.nrows * p.stride + (p.nr * p.ncls + 1) / 2 + 128 + 64 + (size_t)kSearchWaves * kPoolWords) * 4; }   // tables + the waves' job pools
 // staged entries per wave: what the tables leave of the budget (two workgroups per CU), a multiple of 64, 128 at least
 // (one array of packed results or counts; the fill pass also keeps the lines' slot bases)
 static uint32_t search_stage_lines(const SearchChunkDevice &p, int mode) {
@@ -590,9 +706,17 @@ static int launch_search_chunks(const SearchChunkDevice &p, const uint8_t *bytes
     static LdsAttr attr;
     hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(search_chunks_kernel<MODE>), lds, /*at_zero=*/true);
     if (e != hipSuccess) return (int)e;
-    // persistent workgroups: the tables are loaded once per workgroup, its waves take chunk after chunk
+    // persistent workgroups: the tables are loaded once per workgroup, its waves take chunk after chunk.  One workgroup per
+    // CU and no more: a workgroup holds the CU's whole LDS, so a second generation could only start on a CU when all sixteen
+    // waves of the first had finished (measured: four generations cost 8 % on the count pass).
+    static int cus = 0;
+    if (!cus) {
+        int dev_id = 0, n = 0;
+        if (hipGetDevice(&dev_id) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+    }
     size_t blocks = (nchunks + kSearchWaves - 1) / kSearchWaves;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > (size_t)cus) blocks = (size_t)cus;
     hipLaunchKernelGGL(search_chunks_kernel<MODE>, dim3((unsigned)blocks), dim3(kSearchWaves * 64), lds, (hipStream_t)stream, p, bytes, nbytes, chunk_base,
                        nchunks, first, out0, out1, lines, all);
     return (int)hipGetLastError();
