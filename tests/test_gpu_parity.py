@@ -1139,6 +1139,38 @@ def test_search_modes_agree_at_scale():
     assert int(f2[-1]) == st.numel() and torch.equal(f2[:-1], first) and torch.equal(s2, st) and torch.equal(e2, en)
 
 
+def test_search_dense_unanchored_matches_against_the_replay():
+    """Hundreds of hits per 16 KiB chunk whose start has to be walked back to (the wave's job pool fills and is walked 64 jobs at a
+    time, the rest waits; several matches inside one text word; hits met while a lane follows its last line): first match and all
+    matches against the CPU replay of the two search tables, which tests/test_lowering.py pins to the oracle."""
+    from program_replay import SearchReplay
+    rng = np.random.default_rng(23)
+    cases = [("ab+", b"ab \n", [0.45, 0.45, 0.09, 0.01], 384 << 10),          # lines of ~100 bytes, a match every few bytes
+             ("b+c", b"abc\n", [0.3, 0.4, 0.25, 0.05], 256 << 10),            # 20-byte lines, walks of varying length
+             ("[ab]+c", b"abcx\n", [0.4, 0.4, 0.1, 0.07, 0.03], 256 << 10)]   # long walks that stop at an x or at the previous match
+    for pattern, alphabet, prob, n in cases:
+        data = rng.choice(np.frombuffer(alphabet, dtype=np.uint8), size=n, p=prob).astype(np.uint8)
+        data[-1] = 10
+        r = rr.RRegex(pattern)
+        rep = SearchReplay(r.program(rr.PROGRAM_SEARCH_FWD), r.program(rr.PROGRAM_SEARCH_REV))
+        lines = data.tobytes()[:-1].split(b"\n")
+        first_want = [rep.search(ln) for ln in lines]
+        all_want = [rep.search_all(ln) for ln in lines]
+        dev = torch.from_numpy(data).cuda()
+        for stripe in (1024, 0):
+            corpus = rr.Corpus(dev, stripe=stripe)
+            assert corpus.num_lines == len(lines)
+            s, e = r.search_corpus(corpus)
+            got = list(zip(s.cpu().tolist(), e.cpu().tolist()))
+            assert got == first_want, (pattern, stripe, next(i for i, (g, w) in enumerate(zip(got, first_want)) if g != w))
+            cnt, first, st, en = r.search_all(corpus)
+            assert cnt.cpu().tolist() == [len(m) for m in all_want], (pattern, stripe)
+            flat = [m for ms in all_want for m in ms]
+            assert list(zip(st.cpu().tolist(), en.cpu().tolist())) == flat, (pattern, stripe)
+            f2, s2, e2 = r.search_all_fused(corpus)
+            assert int(f2[-1]) == len(flat) and torch.equal(f2[:-1], first) and torch.equal(s2, st) and torch.equal(e2, en), (pattern, stripe)
+
+
 def test_search_all_fused_dense_and_long():
     """rrx_search_all where the staging does not hold a chunk's matches (every byte a match: 16384 per chunk), where a
     line runs over many chunks (its owner counts and places matches far beyond its own bytes), where offsets do not fit

@@ -363,6 +363,9 @@ def test_search_tables_find_the_earliest_ending_leftmost_match():
         fw, rv = r.program(rr.PROGRAM_SEARCH_FWD), r.program(rr.PROGRAM_SEARCH_REV)
         assert fw is not None and rv is not None, p
         rep = SearchReplay(fw, rv)
+        # what the walk-back of search_chunks_kernel relies on (it steps on to the end of its four-byte turn after dying): state 0
+        # of the reverse table is dead for good and not accepting, and a doubled class still fits a byte
+        assert not rep.r.acc[0] and not rep.r.next[0].any() and rep.r.ncls <= 128, p
         alphabet = "abcxk01.d@yz" if p not in (EMAIL, U2) else "ab1.@:/hftps"
         lines = [bytes(ord(ch) for ch in "".join(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 2, 5, 9, 14])))) for _ in range(60)]
         if p == U2:
