@@ -334,8 +334,8 @@ __global__ __launch_bounds__(kThreads) void match_extents_kernel(Program prog, c
     Engine eng;
     eng.load(prog, smem);
     __syncthreads();
-    const size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x;
-    if (i >= nitems) return;
+    // (one item per lane when the grid covers the batch; the predicated fallback is launched with a bounded grid and strides)
+    for (size_t i = (size_t)blockIdx.x * kThreads + threadIdx.x; i < nitems; i += (size_t)gridDim.x * kThreads) {
     size_t b = off[i], e = off[i + 1];
     e = e - b >= trim ? e - trim : b;
     typename Engine::State st;
@@ -356,6 +356,7 @@ __global__ __launch_bounds__(kThreads) void match_extents_kernel(Program prog, c
     }
     for (; p < e && !dead; p++) one(bytes[p]);
     accept[i] = eng.accepting(st) ? 1 : 0;
+    }
 }
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel, device and size increase, not once per launch.
@@ -414,6 +415,7 @@ int launch_extents(const Program &p, size_t table_bytes, const uint8_t *bytes, c
     hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(k), table_bytes);
     if (e != hipSuccess) return (int)e;
     size_t blocks = (nitems + kThreads - 1) / kThreads;
+    if (only_if && blocks > 1024) blocks = 1024;      // the fallback behind the stripe-wise kernel mostly has nothing to do: a grid that ends at once (86 k workgroups: 33 us)
     hipLaunchKernelGGL(k, dim3((unsigned)blocks), dim3(kThreads), table_bytes, (hipStream_t)stream, p, bytes, off, nitems, trim, accept, only_if);
     return (int)hipGetLastError();
 }

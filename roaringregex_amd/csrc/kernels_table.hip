@@ -942,26 +942,32 @@ __global__ __launch_bounds__(kThreads) void match_items_stripes_kernel(LineDfaDe
         if (v) atomicOr(&accept_bits[window_word + i], v);
     }
 }
-// Bitmap of item ends from the offsets (positions relative to off[0]); *flag |= 1 if an item has no byte to carry its mark.
-// The ends are sorted: the 256 items of a workgroup mark a contiguous range of bitmap words, [word of its first mark, word
-// of the next workgroup's first mark].  The range is assembled in LDS, tile by tile, and written out whole - zero words
-// included, consecutive lanes consecutive words - with atomics only for its first and last word, which the neighbouring
-// workgroups share.  (One atomic per item: 0.12 ms for 22 M items of 95 bytes, 1.0 ms for 55 M of 19; one 4-byte store per
-// marked word: 0.34 / 0.83 ms - scattered partial writes into 128 MB.)
+// The index of a batch of items from its offsets, in ONE pass over them (round 3; round 2: a memset of the bitmap, a kernel for
+// the item ends with atomics on the words two workgroups share, and a binary search per stripe):
+//  * ends: bitmap of the item ends (positions relative to off[0]); *flag |= 1 if an item has no byte to carry its mark.  The
+//    ends are sorted: the 1024 items of a workgroup mark a contiguous range of bitmap words, and the workgroup OWNS the words
+//    [word of its first mark, word of the next workgroup's first mark) - it leaves its own last marks that fall into the next
+//    owner's first word to that owner, and picks up the marks the items in front of its own left in its first word (at most 32:
+//    every item has a byte of its own).  The range is assembled in LDS, tile by tile, and written out whole with plain stores,
+//    zero words included: every word of the bitmap is written exactly once, nothing is cleared beforehand, nothing is atomic.
+//    (One atomic per item: 0.12 ms for 22 M items of 95 bytes, 1.0 ms for 55 M of 19; one 4-byte store per marked word:
+//    0.34 / 0.83 ms - scattered partial writes into 128 MB.)
+//  * stripe_base[g] = items that end before stripe g | kFreshStripe if the byte in front of it is marked; entry nstripes = all.
+//    The item that holds a stripe's first byte knows its own number: it writes the entry (no search, no scan); the stripes behind
+//    the batch's last byte (the index is laid out for an upper bound of its extent) are filled in by everybody.
 constexpr uint32_t kEndsTile = 4096, kEndsPerLane = 4, kEndsItems = 256 * kEndsPerLane;      // items per workgroup
-__global__ __launch_bounds__(256) void item_ends_kernel(const uint64_t *__restrict__ off, size_t nitems, uint32_t trim, uint32_t *__restrict__ ends,
-                                                        uint32_t *__restrict__ flag, uint64_t limit_words, const uint8_t *__restrict__ bytes_base,
-                                                        uint64_t min_bytes) {
+__global__ __launch_bounds__(256) void item_index_kernel(const uint64_t *__restrict__ off, size_t nitems, uint32_t trim, uint32_t *__restrict__ ends,
+                                                         uint32_t *__restrict__ flag, uint64_t limit_words, const uint8_t *__restrict__ bytes_base,
+                                                         uint64_t min_bytes, uint32_t stripe_log2, size_t nstripes, uint64_t *__restrict__ stripe_base) {
     __shared__ uint32_t tile[kEndsTile];
+    const uint64_t base = off[0], extent = off[nitems] > base ? off[nitems] - base : 0;
     // one-call form: the batch's extent is only known here.  Unfit (flag bit 1) if it is shorter than the stripe-wise path
     // pays for, longer than the bitmap was sized for, or does not start on a 16-byte boundary.
     if (bytes_base && blockIdx.x == 0 && threadIdx.x == 0) {
-        const uint64_t f = off[0], l = off[nitems];
-        if (l <= f || l - f < min_bytes || ((l - f + 31) >> 5) > limit_words || (reinterpret_cast<uintptr_t>(bytes_base + f) & 15)) atomicOr(flag, 2u);
+        if (!extent || extent < min_bytes || ((extent + 31) >> 5) > limit_words || (reinterpret_cast<uintptr_t>(bytes_base + base) & 15)) atomicOr(flag, 2u);
     }
     const size_t i0 = (size_t)blockIdx.x * kEndsItems;
     const size_t i1 = i0 + kEndsItems < nitems ? i0 + kEndsItems : nitems;     // first item of the next workgroup (nitems: none)
-    const uint64_t base = off[0];
     auto mark_of = [&](size_t k) -> uint64_t {                      // position of item k's mark (a degenerate item: of its start)
         const uint64_t e = off[k + 1];
         return (e > base ? e - 1 : base) - base;
@@ -976,6 +982,7 @@ __global__ __launch_bounds__(256) void item_ends_kernel(const uint64_t *__restri
         oe[k] = i < nitems ? off[i + 1] : 0;
     }
     bool degenerate = false;
+    const uint64_t stripe_mask = ((uint64_t)1 << stripe_log2) - 1;
 #pragma unroll
     for (uint32_t k = 0; k < kEndsPerLane; k++) {
         const size_t i = i0 + (size_t)k * 256 + threadIdx.x;
@@ -983,45 +990,40 @@ __global__ __launch_bounds__(256) void item_ends_kernel(const uint64_t *__restri
         if (i < nitems) {
             if (oe[k] <= ob[k] || oe[k] - ob[k] < trim) degenerate = true;     // trim 1: at least the separator; trim 0: at least one byte
             else { const uint64_t pos = oe[k] - 1 - base; word[k] = pos >> 5; mask[k] = 1u << (pos & 31); }
+            if (oe[k] > ob[k] && ob[k] >= base) {                   // the stripes whose first byte is one of mine
+                const uint64_t s0 = ob[k] - base, e0 = oe[k] - base;
+                uint64_t g = (s0 + stripe_mask) >> stripe_log2;
+                const uint64_t g1 = (e0 + stripe_mask) >> stripe_log2;
+                for (; g < g1 && g < nstripes; g++)
+                    stripe_base[g] = (uint64_t)i | ((g == 0 || (g << stripe_log2) == s0) ? kFreshStripe : 0);
+            }
         }
     }
     if (degenerate) atomicOr(flag, 1u);
-    const uint64_t F = mark_of(i0) >> 5;
-    const uint64_t L = i1 < nitems ? mark_of(i1) >> 5 : mark_of(nitems - 1) >> 5;
-    for (uint64_t T = F; T <= L; T += kEndsTile) {
-        const uint64_t n = L - T + 1 < kEndsTile ? L - T + 1 : kEndsTile;     // words of this tile
+    {   // stripes that begin at or behind the batch's last byte, and the closing entry
+        const uint64_t gend = (extent + stripe_mask) >> stripe_log2;
+        for (uint64_t g = gend + (uint64_t)blockIdx.x * 256 + threadIdx.x; g <= nstripes; g += (uint64_t)gridDim.x * 256)
+            stripe_base[g] = (uint64_t)nitems | ((g < nstripes && (g == 0 || (g << stripe_log2) == extent)) ? kFreshStripe : 0);
+    }
+    const uint64_t F = blockIdx.x == 0 ? 0 : mark_of(i0) >> 5;      // my words: [F, X)
+    uint64_t X = i1 < nitems ? mark_of(i1) >> 5 : ((extent + 31) >> 5) + 4;
+    if (X > limit_words) X = limit_words;
+    for (uint64_t T = F; T < X; T += kEndsTile) {
+        const uint64_t n = X - T < kEndsTile ? X - T : kEndsTile;   // words of this tile
         for (uint32_t j = threadIdx.x; j < n; j += 256) tile[j] = 0;
         __syncthreads();
 #pragma unroll
         for (uint32_t k = 0; k < kEndsPerLane; k++)
-            if (word[k] >= T && word[k] < T + kEndsTile) atomicOr(&tile[(uint32_t)(word[k] - T)], mask[k]);
-        __syncthreads();
-        for (uint32_t j = threadIdx.x; j < n; j += 256) {
-            const uint64_t w = T + j;
-            const uint32_t v = tile[j];
-            if (w >= limit_words) continue;                          // (offsets that overrun the buffer they were sized from)
-            if (w == F || w == L) { if (v) atomicOr(&ends[w], v); }
-            else ends[w] = v;
+            if (word[k] >= T && word[k] < T + n) atomicOr(&tile[(uint32_t)(word[k] - T)], mask[k]);
+        if (T == F && threadIdx.x < 32 && i0 >= 1 + (size_t)threadIdx.x) {      // what the items in front of mine left in my first word
+            const size_t ip = i0 - 1 - threadIdx.x;
+            const uint64_t b = off[ip], e = off[ip + 1];
+            if (e > b && e - b >= trim && e > base && ((e - 1 - base) >> 5) == F) atomicOr(&tile[0], 1u << ((e - 1 - base) & 31));
         }
         __syncthreads();
+        for (uint32_t j = threadIdx.x; j < n; j += 256) ends[T + j] = tile[j];
+        __syncthreads();
     }
-}
-// stripe_base[g] = items that end before stripe g | kFreshStripe if the byte in front of it is marked; entry nstripes = all.
-// The item ends are sorted: a binary search per stripe over the offsets (no count pass over the bitmap, no scan).
-__global__ __launch_bounds__(256) void item_stripe_base_kernel(const uint64_t *__restrict__ off, size_t nitems, uint32_t stripe, size_t nstripes,
-                                                               uint64_t *__restrict__ stripe_base) {
-    const size_t g = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (g > nstripes) return;
-    if (g == nstripes) { stripe_base[g] = nitems; return; }
-    // marks are at off[i + 1] - 1 - off[0]; the number of marks < start = the number of i with off[i + 1] - off[0] <= start
-    const uint64_t base = off[0], target = base + g * (uint64_t)stripe;
-    size_t lo = 0, hi = nitems;                                      // first i with off[i + 1] > target
-    while (lo < hi) {
-        const size_t mid = lo + (hi - lo) / 2;
-        if (off[mid + 1] <= target) lo = mid + 1; else hi = mid;
-    }
-    const bool fresh = g == 0 || (lo > 0 && off[lo] == target);      // the item before ends exactly at my first byte
-    stripe_base[g] = (uint64_t)lo | (fresh ? kFreshStripe : 0);
 }
 
 // ============================================================================================ one long string
@@ -1358,11 +1360,11 @@ int items_index_build(size_t nbytes, const uint64_t *off, size_t nitems, uint32_
     uint32_t *fl = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(index) + items_ends_bytes(nbytes));
     uint64_t *base = reinterpret_cast<uint64_t *>(reinterpret_cast<uint8_t *>(fl) + 256);
     *flag = fl;
-    hipError_t e = hipMemsetAsync(ends, 0, items_ends_bytes(nbytes) + 256, st);       // bitmap and flag
+    if (stripe & (stripe - 1)) return (int)hipErrorInvalidValue;      // (stripes are powers of two)
+    hipError_t e = hipMemsetAsync(fl, 0, 256, st);                    // the flag; the bitmap is written whole by the kernel
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(item_ends_kernel, dim3((unsigned)((nitems + kEndsItems - 1) / kEndsItems)), dim3(256), 0, st, off, nitems, trim, ends, fl,
-                       (uint64_t)(items_ends_bytes(nbytes) / 4), resolve_base, (uint64_t)min_bytes);
-    hipLaunchKernelGGL(item_stripe_base_kernel, dim3((unsigned)((nstripes + 1 + 255) / 256)), dim3(256), 0, st, off, nitems, stripe, nstripes, base);
+    hipLaunchKernelGGL(item_index_kernel, dim3((unsigned)((nitems + kEndsItems - 1) / kEndsItems)), dim3(256), 0, st, off, nitems, trim, ends, fl,
+                       (uint64_t)(items_ends_bytes(nbytes) / 4), resolve_base, (uint64_t)min_bytes, (uint32_t)__builtin_ctz(stripe), nstripes, base);
     return (int)hipGetLastError();
 }
 // one byte per item into `accept` (16-byte aligned); `result` = items_result_bytes(nitems) of scratch.  resolve_off != nullptr:
