@@ -137,8 +137,8 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
                                                                           uint32_t *__restrict__ match_start, uint32_t *__restrict__ match_end,
                                                                           uint32_t kStageLines, SearchAllArgs all) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    // ---- tables into LDS, once per workgroup: its waves then take chunk after chunk (a chunk is only 8 KiB of text, the
-    // tables are up to 46 KiB).  The byte -> column table comes first, at LDS address 0, so that 2 * byte IS its address
+    // ---- tables into LDS, once per workgroup: its waves then take chunk after chunk (a chunk is only 16 KiB of text, the
+    // tables can be several times that).  The byte -> column table comes first, at LDS address 0, so that 2 * byte IS its address
     // (checked below); the forward table's entries get the table's LDS address added: entry.word[0] + column = address.
     const uint32_t t_words = prog.nrows * prog.stride, rev_words = (prog.nr * prog.ncls + 1) / 2;
     uint32_t *C4 = reinterpret_cast<uint32_t *>(smem);            // 128 words
@@ -682,7 +682,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
 
 size_t search_chunk_bytes() { return kSearchChunk; }
 static size_t search_table_bytes(const SearchChunkDevice &p) { return ((size_t)p.nrows * p.stride + (p.nr * p.ncls + 1) / 2 + 128 + 64 + (size_t)kSearchWaves * kPoolWords) * 4; }   // tables + the waves' job pools
-// staged entries per wave: what the tables leave of the budget (two workgroups per CU), a multiple of 64, 128 at least
+// staged entries per wave: what the tables and the job pools leave of the budget (the whole LDS of a CU), a multiple of 64, 128 at least
 // (one array of packed results or counts; the fill pass also keeps the lines' slot bases)
 static uint32_t search_stage_lines(const SearchChunkDevice &p, int mode) {
     const size_t tb = search_table_bytes(p), per = (size_t)kSearchWaves * 4 * ((mode == kFill || mode == kAll) ? 2 : 1);
