@@ -326,6 +326,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     constexpr bool COUNTING = decltype(counting_tag)::value;
     e = e_fwd; ord = ord0; emitted = 0;
     bool owned = fresh, decided = false;                          // the current line: is it mine; kFirst: has its match been found
+    bool fast_count_pass = false;                                 // kCount: the hits added themselves to their lines' staged counts
     if constexpr (MODE == kAll && !COUNTING) { if (fresh) set_first(ord0, lane_base); }
     const uint32_t my_rel = (uint32_t)(my - cstart), my_end_rel = (uint32_t)(my_end - cstart);
     uint32_t ls = my_rel;                                         // its first byte (valid if owned)
@@ -458,9 +459,30 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
         for (int i = 0; i < kEv; i++) emitted += __popc(ev[i] & 0xaaaaaaaau);
         owned = fresh || nl > 0;
     } else {
-    bool fast_first = false;
+    bool fast_first = false, fast_count = false;
     if constexpr (MODE == kFirst) fast_first = hi_ord < (int64_t)kStageLines;      // every line of the chunk has a staged entry ("none" by default)
-    if (fast_first) {
+    if constexpr (MODE == kCount) fast_count = hi_ord < (int64_t)kStageLines;      // ... (0 by default)
+    if (fast_count) {
+        fast_count_pass = true;
+        // matches per line, the common case: only the hits are visited here too - each adds one to its line's staged count (a
+        // line's hits are all its owner's: the lanes behind sit in SKIP until its '\n'), the '\n' events are only counted
+        uint32_t run_ord = ord0, run_ls = my_rel;
+#pragma unroll
+        for (int i = 0; i < kEv; i++) {
+            const uint32_t evw = ev[i];
+            const uint32_t nlm = evw & ~(evw >> 1) & 0x55555555u;
+            uint32_t hm = evw & 0xaaaaaaaau;
+            while (hm) {
+                const int zb = __clz((int)hm);
+                hm &= ~(0x80000000u >> zb);
+                const uint32_t above = zb ? nlm & ~(0xffffffffu >> zb) : 0u;
+                atomicAdd(&st_s[run_ord + (uint32_t)__popc(above)], 1u);
+            }
+            if (nlm) { run_ord += (uint32_t)__popc(nlm); run_ls = my_rel + (uint32_t)(16 * i) + ((uint32_t)(31 - __ffs((int)nlm)) >> 1) + 1u; }
+        }
+        ord = run_ord; ls = run_ls; lb = run_ls; cnt = 0;             // (cnt: what the follow loop adds to my open last line)
+        owned = nl ? run_ls < my_end_rel : fresh;
+    } else if (fast_first) {
         // first match per line, the common case: only the HITS are visited.  The forward table leaves one hit per line (SKIP
         // until the '\n'), every hit among my events is mine (see above), and what a hit needs of the '\n' events - its line's
         // ordinal and first byte - are a popcount and a find-first over the '\n' fields in front of it.  (Round 2 took every
@@ -623,7 +645,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     }
     // my last line, open to the end of the data (or ended by its '\n' beyond my bytes)
     if constexpr (MODE == kFirst) { if (owned && !decided && ord >= kStageLines) emit(ord, kNone, kNone); }
-    if constexpr (MODE == kCount) { if (owned) emit(ord, cnt, 0u); }
+    if constexpr (MODE == kCount) { if (owned) { if (fast_count_pass) atomicAdd(&st_s[ord], cnt); else emit(ord, cnt, 0u); } }
     };      // run_pass
     uint32_t wave_matches = 0;                                    // kAll: matches of the chunk
     if constexpr (MODE == kAll) {
