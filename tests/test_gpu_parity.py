@@ -1171,6 +1171,33 @@ def test_search_dense_unanchored_matches_against_the_replay():
             assert int(f2[-1]) == len(flat) and torch.equal(f2[:-1], first) and torch.equal(s2, st) and torch.equal(e2, en), (pattern, stripe)
 
 
+def test_search_with_tables_beyond_the_chunk_kernels_lds():
+    """`[ab]*a[ab]{11}x`: the product table of the stripe-wise search kernel (8193 rows) does not fit a CU's LDS while the plain forward
+    and reverse tables fit the line-per-lane kernels (round 1's path: line offsets, then a lane per line) - first match, all matches
+    and the one-call form against the CPU replay of the two tables."""
+    from program_replay import SearchReplay
+    pattern = "[ab]*a[ab]{11}x"
+    r = rr.RRegex(pattern)
+    line = r.program(rr.PROGRAM_SEARCH_LINE)
+    assert line is None or int(line[0]) * int(line[1]) * 4 > 160 * 1024          # (else this test no longer reaches the fallback)
+    rep = SearchReplay(r.program(rr.PROGRAM_SEARCH_FWD), r.program(rr.PROGRAM_SEARCH_REV))
+    rng = np.random.default_rng(31)
+    data = rng.choice(np.frombuffer(b"abx\n", dtype=np.uint8), size=200_000, p=[0.45, 0.45, 0.07, 0.03]).astype(np.uint8)
+    data[-1] = 10
+    lines = data.tobytes()[:-1].split(b"\n")
+    first_want = [rep.search(ln) for ln in lines]
+    all_want = [rep.search_all(ln) for ln in lines]
+    assert sum(1 for w in first_want if w[1] >= 0) > 100
+    corpus = rr.Corpus(torch.from_numpy(data).cuda())
+    s, e = r.search_corpus(corpus)
+    assert list(zip(s.cpu().tolist(), e.cpu().tolist())) == first_want
+    cnt, first, st, en = r.search_all(corpus)
+    assert cnt.cpu().tolist() == [len(m) for m in all_want]
+    assert list(zip(st.cpu().tolist(), en.cpu().tolist())) == [m for ms in all_want for m in ms]
+    f2, s2, e2 = r.search_all_fused(corpus)
+    assert int(f2[-1]) == st.numel() and torch.equal(f2[:-1], first) and torch.equal(s2, st) and torch.equal(e2, en)
+
+
 def test_search_all_fused_dense_and_long():
     """rrx_search_all where the staging does not hold a chunk's matches (every byte a match: 16384 per chunk), where a
     line runs over many chunks (its owner counts and places matches far beyond its own bytes), where offsets do not fit
