@@ -943,6 +943,29 @@ def test_explicit_items_stripe_wise():
     assert torch.equal(r.match_extents(dev, off, trim=0), pieces(r, dev, off, 0))
 
 
+def test_explicit_items_inside_a_far_larger_allocation():
+    """rrx_match_extents sizes its index for what is left of the allocation behind d_bytes; with more than 8 GiB left (a batch at
+    the front of a memory pool) it reads the batch's real extent back instead (one synchronisation).  Same answers as on a buffer
+    of the batch's own size, from the front and from the middle of a 10 GiB allocation."""
+    import synth
+    n = 24 << 20
+    host = synth.corpus("url", 12, n)
+    last = int(np.nonzero(host == 10)[0][-1]) + 1
+    host = host[:last]
+    off = torch.from_numpy(np.concatenate([[0], np.nonzero(host == 10)[0] + 1]).astype(np.int64)).cuda()
+    small = torch.from_numpy(host).cuda()
+    r = rr.RRegex(U2)
+    want = r.match_extents(small, off, trim=1)
+    assert int(want.sum()) > 1000
+    pool = torch.empty(10 << 30, dtype=torch.uint8, device="cuda")
+    for at in (0, 6 << 30):                                                  # (6 GiB in: 4 GiB left - the asynchronous path, bound >> extent)
+        pool[at:at + last] = small
+        got = r.match_extents(pool[at:at + last], off, trim=1)
+        assert torch.equal(got, want), at
+    del pool
+    torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------------------------------ one long string
 def test_one_long_string_is_stepped_in_parallel_chunks():
     """regex.h:156-159 consumes ONE string; rrx_match_string cuts a long one into chunks, steps every chunk from every
