@@ -278,7 +278,10 @@ struct rrx_regex {
             for (uint32_t q = 0; q < D; q++)
                 for (uint32_t c = 0; c < stride; c++) {
                     uint32_t v;
-                    if (c <= 128) v = (uint32_t)dfa.next[(size_t)q * dfa.ncls + dfa.cls[c]] * row_bytes;
+                    if (c <= 128) {                                                      // byte 2, bit 7: the row it leads to is accepting (what a trim-0
+                        const uint32_t nx = dfa.next[(size_t)q * dfa.ncls + dfa.cls[c]];  // item that ends on this byte reports; as a shift count it is 0)
+                        v = nx * row_bytes | (dfa.accepting[nx] ? 0x80u << 16 : 0u);
+                    }
                     else if (c == dev::kItemEndColumn) v = dfa.start * row_bytes | 1u << 16 | (dfa.accepting[q] ? 1u << 24 : 0u);
                     else v = 0;                                                          // padding column: never read
                     for (uint32_t k = 0; k < R; k++) T[((size_t)q * stride + c) * R + k] = (v & 0xffff0000u) | ((v & 0xffffu) + 4 * k);

@@ -846,13 +846,15 @@ __global__ __launch_bounds__(kThreads) void match_items_stripes_kernel(LineDfaDe
         typename Engine::State st = fresh ? eng.fresh() : eng.skipping();
         auto end_bit = [&](size_t pos) -> bool { return (ends[pos >> 5] >> (pos & 31)) & 1u; };
         // one byte with its end bit: -> (nl, acc) of the step that matters
+        // (plain entries carry "the next row is accepting" in bit 7 of the byte that is the line count elsewhere: see word())
+        auto step1 = [&](uint32_t c, uint32_t &nl, uint32_t &acc) { eng.step(st, c, nl, acc); nl &= 1u; };
         auto step_byte = [&](size_t pos, uint32_t &nl, uint32_t &acc) {
             uint32_t c = bytes[pos];
             const bool m = end_bit(pos);
             if (c >= 0x80u) c = 0x80u;
             if (ENDS == 1 && m) c = kItemEndColumn;
-            eng.step(st, c, nl, acc);
-            if (ENDS == 2 && m) eng.step(st, kItemEndColumn, nl, acc);
+            step1(c, nl, acc);
+            if (ENDS == 2 && m) step1(kItemEndColumn, nl, acc);
         };
         // a text word (no byte >= 0x81 in it) with the end bits m4 of its four bytes
         auto word = [&](uint32_t w, uint32_t m4) {
@@ -865,13 +867,28 @@ __global__ __launch_bounds__(kThreads) void match_items_stripes_kernel(LineDfaDe
                 }
                 eng.consume_word(st, w, res.bits);
             } else {
-                uint32_t nl, acc;
-#define RRX_ITEM_BYTE(K)                                                                                                  \
-                eng.template consume<K>(st, w, res.bits);                                                                  \
-                if (__builtin_amdgcn_ballot_w64((m4 >> K) & 1u)) {                                                         \
-                    if ((m4 >> K) & 1u) { eng.step(st, kItemEndColumn, nl, acc); res.bits = (res.bits << nl) | acc; }      \
-                }
-                RRX_ITEM_BYTE(0) RRX_ITEM_BYTE(1) RRX_ITEM_BYTE(2) RRX_ITEM_BYTE(3)
+                // trim 0: an item that ends ON this byte reports the verdict of the row the byte leads to and goes back to the start row
+                // - the END column's entry, whose verdict the plain entry carries in bit 23.  So the marked lanes take (start row | one
+                // line | that verdict) in place of what they read: three VALU more per byte, no second lookup, no branch.  (Round 2 and
+                // the first half of round 3 stepped the END column under a wave-wide test per byte: with 64 lanes some lane nearly always
+                // has a mark, so nearly every byte paid two dependent lookups - 12.7 VALU, 5.4 SALU and 1.8 LDS reads per byte.)
+                const uint32_t end_entry = eng.start_off | 1u << 16;
+                uint32_t mk, x, t0, t1;
+#define RRX_ITEM_BYTE(SEL, KBIT)                                                                                                          \
+                asm volatile("v_lshlrev_b32_sdwa %[c4], %[two], %[w] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL "\n\t" \
+                             "v_add_u32_sdwa %[ad], %[e], %[c4] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD\n\t"       \
+                             "ds_read_b32 %[e], %[ad]\n\t"                                                                                  \
+                             "v_bfe_i32 %[mk], %[m4], " KBIT ", 1\n\t"                                                                       \
+                             "s_waitcnt lgkmcnt(0)\n\t"                                                                                     \
+                             "v_and_b32 %[x], 0x800000, %[e]\n\t"                                                                           \
+                             "v_lshl_or_b32 %[x], %[x], 1, %[ee]\n\t"                                                                       \
+                             "v_bfi_b32 %[e], %[mk], %[x], %[e]\n\t"                                                                        \
+                             "v_lshlrev_b32_sdwa %[b], %[e], %[b] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n\t"     \
+                             "v_or_b32_sdwa %[b], %[e], %[b] dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD"              \
+                             : [e] "+v"(st.e), [b] "+v"(res.bits), [c4] "=&v"(t0), [ad] "=&v"(t1), [mk] "=&v"(mk), [x] "=&v"(x)               \
+                             : [w] "v"(w), [two] "v"(eng.col_shift), [m4] "v"(m4), [ee] "v"(end_entry)                                       \
+                             : "memory")
+                RRX_ITEM_BYTE("BYTE_0", "0"); RRX_ITEM_BYTE("BYTE_1", "1"); RRX_ITEM_BYTE("BYTE_2", "2"); RRX_ITEM_BYTE("BYTE_3", "3");
 #undef RRX_ITEM_BYTE
             }
         };
@@ -924,14 +941,14 @@ __global__ __launch_bounds__(kThreads) void match_items_stripes_kernel(LineDfaDe
                         uint32_t c = (w[k >> 2] >> (8 * (k & 3))) & 0xffu;
                         const bool m = (e16 >> k) & 1u;
                         if (ENDS == 1 && m) c = kItemEndColumn;
-                        eng.step(st, c, nl, acc);
-                        if (ENDS == 2 && m) eng.step(st, kItemEndColumn, nl, acc);
+                        step1(c, nl, acc);
+                        if (ENDS == 2 && m) step1(kItemEndColumn, nl, acc);
                     }
                 }
                 pos += 16;
             }
             for (; pos < nbytes && !nl; pos++) step_byte(pos, nl, acc);
-            if (!nl) eng.step(st, kItemEndColumn, nl, acc);            // (cannot happen: the last item ends where the buffer ends)
+            if (!nl) step1(kItemEndColumn, nl, acc);                   // (cannot happen: the last item ends where the buffer ends)
             res.push(nl, acc);
         }
         res.finish();
