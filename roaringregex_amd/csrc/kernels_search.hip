@@ -9,10 +9,13 @@
 //      byte;
 //   2. a wave prefix sum of the lanes' '\n' counts numbers the lines (the chunk's first line number comes from a per-chunk
 //      newline index, as the match kernel's stripes have);
-//   3. the events are replayed in byte order: a '\n' starts the next line, a hit walks the reverse table back from the
-//      match end to the line start (text re-read from L1/L2, 4 bytes per load) and leaves (start, end) in the wave's LDS
-//      staging array at the line's number;
+//   3. the hit events are visited in byte order (first match: the hits only - a hit's line number and line start are a
+//      popcount and a find-first over the '\n' events in front of it; all matches: every event, the '\n' carry the per-line
+//      counts and slots).  A hit whose start is known (the line start / the end of the previous match: a flag of the table)
+//      leaves (start, end) in the wave's LDS staging array at the line's number; any other leaves a JOB in the wave's pool;
 //   4. a lane whose last line is still undecided at the end of its sub-stripe follows it into the next lanes' bytes;
+//      whenever the pool would run over - and at the end - the wave walks 64 jobs at a time, a job per lane, back from the
+//      match end with the reverse table (four bytes per turn, text re-read from L1/L2 as aligned words);
 //   5. the wave writes its lines' results, consecutive lanes consecutive lines: whole sectors, where one lane per stripe
 //      appending 8 bytes per line left them as partial writes (10 ms for the line offsets alone in the first version).
 // ALL matches of every line (rrx_search_all_count / _fill) run the same kernel in two more modes with the "restart" form
