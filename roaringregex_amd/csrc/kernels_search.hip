@@ -734,11 +734,13 @@ static int launch_search_chunks(const SearchChunkDevice &p, const uint8_t *bytes
     // persistent workgroups: the tables are loaded once per workgroup, its waves take chunk after chunk.  One workgroup per
     // CU and no more: a workgroup holds the CU's whole LDS, so a second generation could only start on a CU when all sixteen
     // waves of the first had finished (measured: four generations cost 8 % on the count pass).
-    static int cus = 0;
+    static std::atomic<int> cus_of[kMaxDevices];                  // (per device: 0 = not asked yet)
+    int dev_id = 0;
+    if (hipGetDevice(&dev_id) != hipSuccess) dev_id = 0;
+    int cus = dev_id >= 0 && dev_id < kMaxDevices ? cus_of[dev_id].load(std::memory_order_relaxed) : 0;
     if (!cus) {
-        int dev_id = 0, n = 0;
-        if (hipGetDevice(&dev_id) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess || n <= 0) n = 256;
-        cus = n;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess || cus <= 0) { (void)hipGetLastError(); cus = 256; }
+        if (dev_id >= 0 && dev_id < kMaxDevices) cus_of[dev_id].store(cus, std::memory_order_relaxed);
     }
     size_t blocks = (nchunks + kSearchWaves - 1) / kSearchWaves;
     if (blocks > (size_t)cus) blocks = (size_t)cus;
