@@ -626,6 +626,9 @@ int rrx_compile_ex(const char *pattern, int engine, rrx_regex **out) {
     } catch (const PatternError &e) {
         delete re;
         return fail(RRX_ERR_PATTERN, e.what());
+    } catch (const BudgetError &e) {
+        delete re;
+        return fail(RRX_ERR_UNSUPPORTED, e.what());
     } catch (const std::exception &e) {
         delete re;
         return fail(RRX_ERR_PATTERN, std::string("internal: ") + e.what());

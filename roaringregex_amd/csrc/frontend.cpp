@@ -10,49 +10,109 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <unordered_map>
 
 namespace rrx {
 namespace {
 
 // ------------------------------------------------------------------------------------------ graph
+// The automaton under construction, rows as DAGs of pieces (frontend.hpp).  Every operation costs what it touches, not
+// what the reference's eager copies would: x{1,n} is O(n) pieces where the explicit graph has n^2/2 edges.
 class Graph {
 public:
-    std::vector<std::vector<Edge>> out;          // sorted by .to
-    std::vector<std::vector<uint32_t>> in;       // predecessor ids, sorted
+    std::vector<RowPiece> pieces;
+    std::vector<uint32_t> head;                  // per state
+    std::vector<std::vector<uint32_t>> occ;      // occ[t]: the pieces that hold a direct edge to t (each once)
+    uint64_t work = 0;                           // pieces + direct edges made so far
 
     void ensure(uint64_t upto) {
         if (upto > kMaxStates) throw PatternError("too many states (> 65536)");
-        if (out.size() < upto) { out.resize(upto); in.resize(upto); }
+        if (head.size() < upto) { head.resize(upto, kNoPiece); occ.resize(upto); }
     }
-    void connect(uint32_t s, uint32_t t, const CharSet &on) {
+    void spend(uint64_t units) {
+        work += units;
+        if (work > kFrontEndBudget) throw BudgetError("pattern too large: the automaton exceeds the front end's work budget");
+    }
+    uint32_t new_piece() {
+        spend(1);
+        pieces.emplace_back();
+        return (uint32_t)pieces.size() - 1;
+    }
+    void add_direct(uint32_t piece, uint32_t t, const CharSet &on) {
         if (on.empty()) return;
-        auto &o = out[s];
-        auto it = std::lower_bound(o.begin(), o.end(), t, [](const Edge &e, uint32_t v) { return e.to < v; });
-        if (it != o.end() && it->to == t) it->on |= on;
+        auto &d = pieces[piece].direct;
+        auto it = std::lower_bound(d.begin(), d.end(), t, [](const Edge &e, uint32_t v) { return e.to < v; });
+        if (it != d.end() && it->to == t) it->on |= on;
         else {
-            o.insert(it, Edge{t, on});
-            auto &p = in[t];
-            auto jt = std::lower_bound(p.begin(), p.end(), s);
-            if (jt == p.end() || *jt != s) p.insert(jt, s);
+            spend(1);
+            d.insert(it, Edge{t, on});
+            occ[t].push_back(piece);
         }
     }
-    CharSet label(uint32_t s, uint32_t t) const {
-        const auto &o = out[s];
-        auto it = std::lower_bound(o.begin(), o.end(), t, [](const Edge &e, uint32_t v) { return e.to < v; });
-        return (it != o.end() && it->to == t) ? it->on : CharSet();
+    // an edge out of a state nobody has copied from yet (atoms: NFA.cc:50-71)
+    void connect_fresh(uint32_t s, uint32_t t, const CharSet &on) {
+        if (head[s] == kNoPiece) head[s] = new_piece();
+        add_direct(head[s], t, on);
     }
-    // NFA.cc:108-121 skip<true>(n,k): n takes over every out-edge of k ("eps n->k", resolved eagerly).
+    // NFA.cc:108-121 skip<true>(n,k): n takes over every out-edge k has NOW ("eps n->k", resolved eagerly).
     void inherit_out(uint32_t n, uint32_t k) {
-        if (n == k) return;
-        std::vector<Edge> snap = out[k];
-        for (const Edge &e : snap) connect(n, e.to, e.on);
+        if (n == k || head[k] == kNoPiece) return;
+        const uint32_t hk = head[k];
+        if (head[n] == kNoPiece) head[n] = new_piece();
+        else if (pieces[head[n]].shared) {       // somebody holds a snapshot of row(n): it must not grow with n
+            const uint32_t old = head[n], fresh = new_piece();
+            pieces[fresh].children.push_back(old);
+            head[n] = fresh;
+        }
+        auto &ch = pieces[head[n]].children;
+        if (std::find(ch.begin(), ch.end(), hk) == ch.end()) { spend(1); ch.push_back(hk); }
+        pieces[hk].shared = true;
     }
-    // NFA.cc:108-121 skip<false>(n,k): whatever enters n also enters k, on the same characters.
+    // NFA.cc:108-121 skip<false>(n,k): whatever enters n also enters k, on the same characters.  A state j enters n on
+    // the OR of the labels n carries in the pieces of row(j); adding k beside every such entry gives j exactly that.
     void mirror_in(uint32_t n, uint32_t k) {
         if (n == k) return;
-        std::vector<uint32_t> preds = in[n];
-        for (uint32_t j : preds) connect(j, k, label(j, n));
+        const std::vector<uint32_t> holders = occ[n];
+        for (uint32_t piece : holders) {
+            const auto &d = pieces[piece].direct;
+            auto it = std::lower_bound(d.begin(), d.end(), n, [](const Edge &e, uint32_t v) { return e.to < v; });
+            const CharSet on = it->on;
+            add_direct(piece, k, on);
+        }
     }
+    // NFA.cc:177-185: the states [lo, lo+size) again at [lo+rot, ...).  A fragment on the stack is self-contained (no edge
+    // leaves its state range, nobody outside holds one of its pieces), so its pieces are copied one for one, sharing kept.
+    void copy_shifted(uint32_t lo, uint32_t size, uint32_t rot) {
+        std::vector<uint32_t> stack;
+        auto copy_of = [&](uint32_t old) -> int64_t {
+            auto it = copied.find(old);
+            return it == copied.end() ? -1 : (int64_t)it->second;
+        };
+        copied.clear();
+        for (uint32_t s = lo; s < lo + size; s++) {
+            if (head[s] == kNoPiece) continue;
+            stack.push_back(head[s]);
+            while (!stack.empty()) {                              // post-order without recursion: chains are thousands deep
+                const uint32_t p = stack.back();
+                if (copy_of(p) >= 0) { stack.pop_back(); continue; }
+                bool ready = true;
+                for (uint32_t c : pieces[p].children) if (copy_of(c) < 0) { stack.push_back(c); ready = false; }
+                if (!ready) continue;
+                stack.pop_back();
+                const uint32_t q = new_piece();
+                spend(pieces[p].direct.size() + pieces[p].children.size());
+                pieces[q].shared = pieces[p].shared;
+                pieces[q].direct = pieces[p].direct;
+                for (Edge &e : pieces[q].direct) { e.to += rot; occ[e.to].push_back(q); }
+                pieces[q].children.reserve(pieces[p].children.size());
+                for (uint32_t c : pieces[p].children) pieces[q].children.push_back((uint32_t)copy_of(c));
+                copied.emplace(p, q);
+            }
+            head[s + rot] = (uint32_t)copy_of(head[s]);
+        }
+    }
+private:
+    std::unordered_map<uint32_t, uint32_t> copied;
 };
 
 // A sub-automaton occupying states [initial, initial+size): regex.h:78-96 + final_states (regex.h:177).
@@ -175,7 +235,7 @@ class Machine {
     }
     Frag atom(uint32_t at, const CharSet &on) {
         g.ensure((uint64_t)at + 2);
-        g.connect(at, at + 1, on);
+        g.connect_fresh(at, at + 1, on);
         Frag f; f.initial = at; f.size = 2; f.finals = {at + 1};
         return f;
     }
@@ -205,10 +265,7 @@ class Machine {
     Frag shifted_copy(const Frag &a) {
         const uint32_t rot = a.size;
         g.ensure((uint64_t)a.initial + rot + a.size);
-        for (uint32_t s = a.initial; s < a.initial + a.size; s++) {
-            std::vector<Edge> snap = g.out[s];
-            for (const Edge &e : snap) g.connect(s + rot, e.to + rot, e.on);
-        }
+        g.copy_shifted(a.initial, a.size, rot);
         Frag r; r.initial = a.initial + rot; r.size = a.size;
         r.finals.reserve(a.finals.size());
         for (uint32_t f : a.finals) r.finals.push_back(f + rot);
@@ -293,18 +350,52 @@ public:
         g.ensure(a.states_n);
         a.is_final.assign(a.states_n, 0);
         for (uint32_t s : f.finals) if (s < a.states_n) a.is_final[s] = 1;
-        a.out = std::move(g.out);
-        a.out.resize(a.states_n);
+        a.pieces = std::move(g.pieces);
+        a.head = std::move(g.head);
+        a.head.resize(a.states_n, kNoPiece);
         return a;
     }
 };
 
 }  // namespace
 
+namespace {
+// the pieces of row(state), each once
+template <class F> void for_each_piece(const RefAutomaton &a, uint32_t state, F &&f) {
+    if (state >= a.states_n || a.head[state] == kNoPiece) return;
+    thread_local std::vector<uint32_t> stamp;
+    thread_local uint32_t epoch = 0;
+    if (stamp.size() < a.pieces.size()) stamp.resize(a.pieces.size(), 0);
+    if (++epoch == 0) { std::fill(stamp.begin(), stamp.end(), 0u); epoch = 1; }
+    std::vector<uint32_t> stack{a.head[state]};
+    stamp[a.head[state]] = epoch;
+    while (!stack.empty()) {
+        const uint32_t p = stack.back(); stack.pop_back();
+        f(a.pieces[p]);
+        for (uint32_t c : a.pieces[p].children) if (stamp[c] != epoch) { stamp[c] = epoch; stack.push_back(c); }
+    }
+}
+}  // namespace
+
 std::vector<uint32_t> RefAutomaton::row(uint32_t state, unsigned c) const {
     std::vector<uint32_t> r;
-    if (state >= states_n || c >= 128) return r;
-    for (const Edge &e : out[state]) if (e.on.has(c)) r.push_back(e.to);
+    if (c >= 128) return r;
+    for_each_piece(*this, state, [&](const RowPiece &p) { for (const Edge &e : p.direct) if (e.on.has(c)) r.push_back(e.to); });
+    std::sort(r.begin(), r.end());
+    r.erase(std::unique(r.begin(), r.end()), r.end());
+    return r;
+}
+
+std::vector<Edge> RefAutomaton::expand_row(uint32_t state) const {
+    std::vector<Edge> r;
+    for_each_piece(*this, state, [&](const RowPiece &p) { r.insert(r.end(), p.direct.begin(), p.direct.end()); });
+    std::sort(r.begin(), r.end(), [](const Edge &x, const Edge &y) { return x.to < y.to; });
+    size_t w = 0;
+    for (size_t i = 0; i < r.size(); i++) {
+        if (w && r[w - 1].to == r[i].to) r[w - 1].on |= r[i].on;
+        else r[w++] = r[i];
+    }
+    r.resize(w);
     return r;
 }
 

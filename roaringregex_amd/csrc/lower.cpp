@@ -5,47 +5,274 @@
 #include <cstring>
 #include <map>
 #include <queue>
+#include <unordered_map>
 
 namespace rrx {
 
 // ------------------------------------------------------------------------------------------ trim
+// The useful part of the reference automaton, taken from its UNEXPANDED rows (frontend.hpp: a row is a DAG of shared pieces).
+// Reachability and co-reachability are exact and cost the pieces, not the edges.  The rows that come out are the explicit
+// rows minus DOMINATED edges: u->w goes when a sibling u->v stays with label(w) a subset of label(v) and L(v) a superset of
+// L(w) (the words accepted from it) - then u->w adds no word to L(u), so every state keeps its language whatever else has been
+// dropped before.  L(v) >= L(w) is known when w is final only if v is and
+//   * row(w) is empty, or the head piece of w is one of the pieces row(v) is made of (v took a copy of w's row: the skipped
+//     tail of every nullable fold - x{1,n} leaves n^2/2 such edges, Parser.cpp:123-141), or
+//   * to a small depth: every kept edge of w has a kept edge of v with a label above it into the same state or one that
+//     dominates it by these same rules ((ab){1,n}: the state after `a` of copy i over that of copy i+1).
+// The pruned row of a piece is made from its own edges and the PRUNED rows of its children, children and target rows first
+// (explicit stack: chains are tens of thousands deep), so x{1,n} costs O(n) here too.
+namespace {
+
+struct PieceTrimmer {
+    const RefAutomaton &a;
+    const std::vector<uint8_t> &useful;
+    std::vector<uint8_t> st;                       // 0 = not visited, 1 = on the stack, 2 = done
+    std::vector<std::vector<Edge>> pe;             // pruned expansion per piece (targets: useful reference states, no NUL)
+    std::vector<CharSet> first;                    // the characters pe[piece] moves on
+    uint64_t pair_tests = 0;
+    std::vector<uint32_t> desc_stack;
+
+    PieceTrimmer(const RefAutomaton &a_, const std::vector<uint8_t> &u) : a(a_), useful(u), st(a_.pieces.size(), 0), pe(a_.pieces.size()), first(a_.pieces.size()) {}
+
+    static CharSet strip(CharSet on) { on.w[0] &= ~1ULL; return on; }           // NUL never occurs inside a string (regex.h:157)
+    static bool subset(const CharSet &x, const CharSet &y) { return !(x.w[0] & ~y.w[0]) && !(x.w[1] & ~y.w[1]); }
+
+    // "piece `what` is one of the pieces `from` is made of": exact along a spanning forest of the child links (pre / post
+    // numbers: what chains of nullable copies give), then a short search for pieces with several parents.  A miss only
+    // keeps an edge.
+    std::vector<uint32_t> pre, post;
+    void number_forest() {
+        const uint32_t P = (uint32_t)a.pieces.size();
+        pre.assign(P, UINT32_MAX); post.assign(P, 0);
+        std::vector<uint8_t> has_parent(P, 0);
+        for (uint32_t p = 0; p < P; p++) for (uint32_t c : a.pieces[p].children) has_parent[c] = 1;
+        uint32_t clock = 0;
+        std::vector<std::pair<uint32_t, uint32_t>> stack;          // (piece, next child)
+        for (uint32_t r = 0; r < P; r++) {
+            if (has_parent[r] || pre[r] != UINT32_MAX) continue;
+            pre[r] = clock++;
+            stack.emplace_back(r, 0);
+            while (!stack.empty()) {
+                const uint32_t p = stack.back().first;
+                if (stack.back().second < a.pieces[p].children.size()) {
+                    const uint32_t c = a.pieces[p].children[stack.back().second++];
+                    if (pre[c] == UINT32_MAX) { pre[c] = clock++; stack.emplace_back(c, 0); }
+                } else { post[p] = clock; stack.pop_back(); }
+            }
+        }
+    }
+    bool is_descendant(uint32_t from, uint32_t what) {
+        if (pre[from] < pre[what] && pre[what] < post[from]) return true;
+        if (!a.pieces[what].shared) return false;
+        desc_stack.assign(1, from);
+        int budget = 12;
+        while (!desc_stack.empty() && budget-- > 0) {
+            const uint32_t p = desc_stack.back(); desc_stack.pop_back();
+            for (uint32_t c : a.pieces[p].children) {
+                if (c == what || (pre[c] < pre[what] && pre[what] < post[c])) return true;
+                desc_stack.push_back(c);
+            }
+        }
+        return false;
+    }
+    // The recursive rule is COINDUCTIVE: a pair met again while it is being proven counts as holding (loops inside the
+    // repeated operand: (a+b+){1,n} needs "the a-loop of copy i over the a-loop of copy j" to prove itself).  A success that
+    // leans on a pair still in progress further up is only as good as that pair: it is handed up (`leans`), never cached;
+    // successes that lean on nothing outside their own proof, and all failures (an assumption can only help), are cached.
+    std::unordered_map<uint64_t, uint8_t> memo;                 // (v, w, depth) -> 1 no / 2 yes
+    std::vector<std::pair<uint32_t, uint32_t>> in_progress;
+    bool dominates(uint32_t v, uint32_t w, int depth, uint32_t &leans) {       // L(v) >= L(w), proven
+        leans = UINT32_MAX;
+        if (a.is_final[w] && !a.is_final[v]) return false;
+        const uint32_t hw = a.head[w], hv = a.head[v];
+        if (hw == kNoPiece) return true;
+        if (st[hw] == 2 && pe[hw].empty()) return true;
+        if (hv == kNoPiece) return false;
+        if (is_descendant(hv, hw)) return true;
+        if (depth == 0 || st[hv] != 2 || st[hw] != 2 || pair_tests > kTrimPairTests) return false;
+        if (!subset(first[hw], first[hv])) return false;           // w can start with a character v cannot
+        for (uint32_t i = 0; i < in_progress.size(); i++) if (in_progress[i].first == v && in_progress[i].second == w) { leans = i; return true; }
+        const std::vector<Edge> &rv = pe[hv], &rw = pe[hw];
+        if (rw.size() * rv.size() > 64) return false;
+        const uint64_t key = ((uint64_t)v << 34) | ((uint64_t)w << 4) | (uint64_t)depth;
+        auto it = memo.find(key);
+        if (it != memo.end()) return it->second == 2;
+        pair_tests += rw.size() * rv.size();
+        const uint32_t me = (uint32_t)in_progress.size();
+        in_progress.emplace_back(v, w);
+        bool all = true;
+        uint32_t lowest = UINT32_MAX;
+        for (const Edge &e : rw) {
+            bool found = false;
+            for (const Edge &f : rv) {
+                if (!subset(e.on, f.on)) continue;
+                if (f.to == e.to) { found = true; break; }
+                uint32_t l;
+                if (dominates(f.to, e.to, depth - 1, l)) { lowest = std::min(lowest, l); found = true; break; }
+            }
+            if (!found) { all = false; break; }
+        }
+        in_progress.pop_back();
+        if (!all) { memo.emplace(key, 1); return false; }
+        if (lowest >= me) memo.emplace(key, 2);                 // leans on itself at most
+        else leans = lowest;
+        return true;
+    }
+    void raw_expand(uint32_t root, std::vector<Edge> &out) {                    // a child that is still on the stack (a cycle)
+        std::vector<uint32_t> stack{root}, seen{root};
+        while (!stack.empty()) {
+            const uint32_t p = stack.back(); stack.pop_back();
+            for (const Edge &e : a.pieces[p].direct) { const CharSet on = strip(e.on); if (useful[e.to] && !on.empty()) out.push_back(Edge{e.to, on}); }
+            for (uint32_t c : a.pieces[p].children) if (std::find(seen.begin(), seen.end(), c) == seen.end()) { seen.push_back(c); stack.push_back(c); }
+        }
+    }
+    std::vector<uint32_t> n_parents;               // pieces that list it as a child
+    std::vector<uint8_t> heads_useful;             // it is the head piece of a useful state
+    uint64_t visited_edges = 0, live_edges = 0;
+    void build(uint32_t p) {
+        // candidates with their origin: 0 = the piece's own edges, k = its k-th child (whose row is pruned within itself
+        // already: only pairs of different origin are compared - an alternation of 1000 keywords is a chain of 1000 pieces,
+        // each adding one edge to a row of hundreds)
+        std::vector<Edge> cand;
+        std::vector<uint16_t> origin;
+        for (const Edge &e : a.pieces[p].direct) { const CharSet on = strip(e.on); if (useful[e.to] && !on.empty()) cand.push_back(Edge{e.to, on}); }
+        origin.assign(cand.size(), 0);
+        uint32_t k = 0;
+        for (uint32_t c : a.pieces[p].children) {
+            k++;
+            if (st[c] == 2) {
+                cand.insert(cand.end(), pe[c].begin(), pe[c].end());
+                if (n_parents[c] == 1 && !heads_useful[c]) { live_edges -= pe[c].size(); std::vector<Edge>().swap(pe[c]); }    // nobody else reads it
+            } else raw_expand(c, cand);
+            origin.resize(cand.size(), (uint16_t)std::min<uint32_t>(k, 0xfffe));
+        }
+        visited_edges += cand.size();
+        std::vector<uint32_t> idx(cand.size());
+        for (uint32_t i = 0; i < idx.size(); i++) idx[i] = i;
+        std::stable_sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return cand[x].to < cand[y].to; });
+        std::vector<Edge> merged;
+        std::vector<uint16_t> from;                 // 0xffff: the target came from several origins
+        for (uint32_t i : idx) {
+            if (!merged.empty() && merged.back().to == cand[i].to) { merged.back().on |= cand[i].on; if (from.back() != origin[i]) from.back() = 0xffff; }
+            else { merged.push_back(cand[i]); from.push_back(origin[i]); }
+        }
+        const size_t n = merged.size();
+        std::vector<uint8_t> dropped(n, 0);
+        if (n > 1) {
+            // dominators are tried in this order: the piece's own edges first (the copy taken, not the tail skipped to)
+            std::vector<uint32_t> order, order_own;
+            for (uint32_t i = 0; i < n; i++) if (from[i] == 0 || from[i] == 0xffff) order.push_back(i);
+            order_own = order;
+            for (uint32_t i = 0; i < n; i++) if (from[i] != 0 && from[i] != 0xffff) order.push_back(i);
+            const size_t per_edge = n <= 64 ? n : std::max<size_t>(8, 4096 / n);
+            for (uint32_t w = 0; w < n; w++) {
+                size_t tried = 0;
+                // an edge that came from the only child has been compared with its fellows there: the own edges are left
+                const bool own_only = k == 1 && from[w] == 1;
+                for (uint32_t v : own_only ? order_own : order) {
+                    if (v == w || dropped[v] || !subset(merged[w].on, merged[v].on)) continue;
+                    if (from[v] == from[w] && from[v] != 0 && from[v] != 0xffff) continue;      // compared when that child was built
+                    if (++tried > per_edge) break;
+                    uint32_t leans;
+                    if (dominates(merged[v].to, merged[w].to, 6, leans)) { dropped[w] = 1; break; }
+                }
+            }
+        }
+        std::vector<Edge> &out = pe[p];
+        for (uint32_t i = 0; i < n; i++) if (!dropped[i]) out.push_back(merged[i]);
+        live_edges += out.size();
+        for (const Edge &e : out) first[p] |= e.on;
+        if (live_edges > kTrimBudget || visited_edges > 32 * kTrimBudget)
+            throw BudgetError("pattern too large: the automaton's rows exceed the host pipeline's work budget");
+    }
+    void run(uint32_t root) {
+        if (st[root]) return;
+        std::vector<uint32_t> stack{root};
+        while (!stack.empty()) {
+            const uint32_t p = stack.back();
+            if (st[p] == 2) { stack.pop_back(); continue; }
+            st[p] = 1;
+            bool pushed = false;
+            for (uint32_t c : a.pieces[p].children) if (st[c] == 0) { stack.push_back(c); pushed = true; }
+            for (const Edge &e : a.pieces[p].direct) {
+                if (!useful[e.to] || strip(e.on).empty()) continue;
+                const uint32_t h = a.head[e.to];
+                if (h != kNoPiece && st[h] == 0) { stack.push_back(h); pushed = true; }
+            }
+            if (pushed) continue;
+            build(p);
+            st[p] = 2;
+            stack.pop_back();
+        }
+    }
+};
+
+}  // namespace
+
 Trimmed trim(const RefAutomaton &a) {
     Trimmed t;
     std::memset(t.cls, 0, sizeof t.cls);
     t.cls_rep.assign(1, 0);
-    const uint32_t N = a.states_n;
-    // NUL never occurs inside a string (regex.h:157 stops on it), so transitions on it are unreachable.
-    std::vector<std::vector<Edge>> out(N);
-    for (uint32_t s = 0; s < N; s++)
-        for (Edge e : a.out[s]) {
-            e.on.w[0] &= ~1ULL;
-            if (!e.on.empty() && e.to < N) out[s].push_back(e);
-        }
-    std::vector<uint8_t> fwd(N, 0), bwd(N, 0);
-    std::vector<uint32_t> stack;
+    const uint32_t N = a.states_n, P = (uint32_t)a.pieces.size();
+    auto live_edge = [&](const Edge &e) { CharSet on = e.on; on.w[0] &= ~1ULL; return !on.empty() && e.to < N; };
+    // ---- reachable from the initial state: every piece is walked once
+    std::vector<uint8_t> fwd(N, 0), bwd(N, 0), seen(P, 0);
+    std::vector<uint32_t> stack, pstack;
     if (a.initial < N) { fwd[a.initial] = 1; stack.push_back(a.initial); }
     while (!stack.empty()) {
-        uint32_t s = stack.back(); stack.pop_back();
-        for (const Edge &e : out[s]) if (!fwd[e.to]) { fwd[e.to] = 1; stack.push_back(e.to); }
+        const uint32_t s = stack.back(); stack.pop_back();
+        if (a.head[s] == kNoPiece || seen[a.head[s]]) continue;
+        seen[a.head[s]] = 1; pstack.push_back(a.head[s]);
+        while (!pstack.empty()) {
+            const uint32_t p = pstack.back(); pstack.pop_back();
+            for (const Edge &e : a.pieces[p].direct) if (live_edge(e) && !fwd[e.to]) { fwd[e.to] = 1; stack.push_back(e.to); }
+            for (uint32_t c : a.pieces[p].children) if (!seen[c]) { seen[c] = 1; pstack.push_back(c); }
+        }
     }
-    std::vector<std::vector<uint32_t>> pred(N);
-    for (uint32_t s = 0; s < N; s++) for (const Edge &e : out[s]) pred[e.to].push_back(s);
-    for (uint32_t s = 0; s < N; s++) if (a.is_final[s]) { bwd[s] = 1; stack.push_back(s); }
-    while (!stack.empty()) {
-        uint32_t s = stack.back(); stack.pop_back();
-        for (uint32_t p : pred[s]) if (!bwd[p]) { bwd[p] = 1; stack.push_back(p); }
+    // ---- able to reach a final state: backwards over (target -> pieces that hold it -> pieces that include those -> owners)
+    {
+        std::vector<std::vector<uint32_t>> holders(N), parents(P), owners(P);
+        for (uint32_t p = 0; p < P; p++) {
+            for (const Edge &e : a.pieces[p].direct) if (live_edge(e)) holders[e.to].push_back(p);
+            for (uint32_t c : a.pieces[p].children) parents[c].push_back(p);
+        }
+        for (uint32_t s = 0; s < N; s++) if (a.head[s] != kNoPiece) owners[a.head[s]].push_back(s);
+        std::vector<uint8_t> live(P, 0);
+        for (uint32_t s = 0; s < N; s++) if (a.is_final[s]) { bwd[s] = 1; stack.push_back(s); }
+        while (!stack.empty()) {
+            const uint32_t s = stack.back(); stack.pop_back();
+            for (uint32_t h : holders[s]) {
+                if (live[h]) continue;
+                live[h] = 1; pstack.push_back(h);
+                while (!pstack.empty()) {
+                    const uint32_t p = pstack.back(); pstack.pop_back();
+                    for (uint32_t o : owners[p]) if (!bwd[o]) { bwd[o] = 1; stack.push_back(o); }
+                    for (uint32_t q : parents[p]) if (!live[q]) { live[q] = 1; pstack.push_back(q); }
+                }
+            }
+        }
     }
     if (a.initial >= N || !(fwd[a.initial] && bwd[a.initial])) return t;   // empty language
+    std::vector<uint8_t> useful(N, 0);
     std::vector<int64_t> newid(N, -1);
-    for (uint32_t s = 0; s < N; s++) if (fwd[s] && bwd[s]) { newid[s] = (int64_t)t.ref_id.size(); t.ref_id.push_back(s); }
+    for (uint32_t s = 0; s < N; s++) if (fwd[s] && bwd[s]) { useful[s] = 1; newid[s] = (int64_t)t.ref_id.size(); t.ref_id.push_back(s); }
     t.n = (uint32_t)t.ref_id.size();
     t.initial = (uint32_t)newid[a.initial];
     t.is_final.assign(t.n, 0);
     t.out.assign(t.n, {});
+    PieceTrimmer pt(a, useful);
+    pt.number_forest();
+    pt.n_parents.assign(P, 0);
+    pt.heads_useful.assign(P, 0);
+    for (uint32_t p = 0; p < P; p++) for (uint32_t c : a.pieces[p].children) pt.n_parents[c]++;
+    for (uint32_t s = 0; s < N; s++) if (useful[s] && a.head[s] != kNoPiece) pt.heads_useful[a.head[s]] = 1;
+    if (a.head[a.initial] != kNoPiece) pt.run(a.head[a.initial]);
     for (uint32_t k = 0; k < t.n; k++) {
-        uint32_t s = t.ref_id[k];
+        const uint32_t s = t.ref_id[k];
         t.is_final[k] = a.is_final[s];
-        for (const Edge &e : out[s]) if (newid[e.to] >= 0) t.out[k].push_back(Edge{(uint32_t)newid[e.to], e.on});
+        if (a.head[s] == kNoPiece) continue;
+        pt.run(a.head[s]);
+        for (const Edge &e : pt.pe[a.head[s]]) t.out[k].push_back(Edge{(uint32_t)newid[e.to], e.on});
     }
     // byte classes = atoms of the boolean algebra generated by the edge labels
     std::vector<CharSet> labels;
@@ -110,71 +337,113 @@ bool quotient(std::vector<Node> &nodes, bool forward) {
         std::vector<uint32_t> tmp = block; sort_unique(tmp); count = (uint32_t)tmp.size();
     }
     // Partition refinement with a worklist: a round only looks at the DIRTY nodes (those with a neighbour that changed
-    // block in the round before); the others still carry their block's signature.  The plain "recompute every signature
-    // until nothing splits" form took one round per node on a chain of equal labels - x{17000} is 17000 rounds over
-    // 17000 nodes (154 s for one compile); this one does O(1) work per round there.  The result is the same partition
-    // (the coarsest stable refinement is unique).
+    // block in the round before); the others still carry their block's signature (the set of their neighbours' blocks).
+    // The plain "recompute every signature until nothing splits" form took one round per node on a chain of equal labels
+    // (x{17000}: 154 s); recomputing only dirty signatures still cost a node of in-degree d its d neighbours in every
+    // round it was dirty ((ab?){1,n}: one round per copy, the last node entered from all of them: n^2).  So the signature
+    // is kept incrementally: per node a sorted list (neighbour block, how many neighbours in it) and a 64-bit sum of
+    // mix(block) over the blocks present; a neighbour's move updates two entries.  Nodes are grouped by (block, sum); the
+    // partition that comes out is then CHECKED against the real signatures (below), so a collision cannot merge what must
+    // stay apart.  The result is the coarsest stable refinement (unique).
     std::vector<std::vector<uint32_t>> dep(n);             // dep[v]: the nodes whose signature mentions v
     for (uint32_t u = 0; u < n; u++) for (uint32_t v : nb[u]) dep[v].push_back(u);
     std::vector<std::vector<uint32_t>> members(count);
     std::vector<uint32_t> where(n);
     for (uint32_t u = 0; u < n; u++) { where[u] = (uint32_t)members[block[u]].size(); members[block[u]].push_back(u); }
-    std::vector<uint8_t> is_dirty(n, 1), queued(n, 0);
-    std::vector<uint32_t> dirty(n), next_dirty;
-    for (uint32_t u = 0; u < n; u++) dirty[u] = u;
-    auto signature = [&](uint32_t u) {
-        std::vector<uint32_t> sig;
-        sig.reserve(nb[u].size() + 1);
-        sig.push_back(block[u]);                           // own block first: a block's groups are neighbours in the map
-        for (uint32_t v : nb[u]) sig.push_back(block[v]);
-        std::sort(sig.begin() + 1, sig.end());
-        sig.erase(std::unique(sig.begin() + 1, sig.end()), sig.end());
-        return sig;
-    };
-    struct Split { std::vector<uint32_t> rep_sig; bool has_rep = false; };
-    while (!dirty.empty()) {
-        std::map<std::vector<uint32_t>, std::vector<uint32_t>> groups;
-        for (uint32_t u : dirty) groups[signature(u)].push_back(u);
-        // a block that also has clean members keeps its id for them: their signature, taken from one of them, BEFORE any
-        // node moves in this round
-        std::map<uint32_t, Split> reps;
-        {
-            std::map<uint32_t, uint32_t> ndirty;
-            for (auto &g : groups) ndirty[g.first[0]] += (uint32_t)g.second.size();
-            for (auto &kv : ndirty) {
-                if (kv.second == members[kv.first].size()) continue;
-                for (uint32_t u : members[kv.first])
-                    if (!is_dirty[u]) { Split &sp = reps[kv.first]; sp.rep_sig = signature(u); sp.has_rep = true; break; }
-            }
+    auto mix = [](uint32_t b) { uint64_t z = (uint64_t)b + 0x9e3779b97f4a7c15ULL; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL; z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; return z ^ (z >> 31); };
+    std::vector<std::vector<std::pair<uint32_t, uint32_t>>> cnt(n);       // sorted by block
+    std::vector<uint64_t> sum(n, 0);
+    for (uint32_t u = 0; u < n; u++) {
+        std::vector<uint32_t> bl;
+        bl.reserve(nb[u].size());
+        for (uint32_t v : nb[u]) bl.push_back(block[v]);
+        std::sort(bl.begin(), bl.end());
+        for (size_t i = 0; i < bl.size();) {
+            size_t j = i;
+            while (j < bl.size() && bl[j] == bl[i]) j++;
+            cnt[u].emplace_back(bl[i], (uint32_t)(j - i));
+            sum[u] += mix(bl[i]);
+            i = j;
         }
+    }
+    auto bump = [&](uint32_t u, uint32_t b, int by) {
+        auto &c = cnt[u];
+        auto it = std::lower_bound(c.begin(), c.end(), std::make_pair(b, 0u));
+        if (it != c.end() && it->first == b) {
+            it->second = (uint32_t)((int64_t)it->second + by);
+            if (!it->second) { c.erase(it); sum[u] -= mix(b); }
+        } else { c.insert(it, std::make_pair(b, 1u)); sum[u] += mix(b); }      // (by = +1)
+    };
+    std::vector<uint8_t> is_dirty(n, 1), queued(n, 0);
+    std::vector<uint32_t> dirty(n), next_dirty, moved, moved_from, moved_to;
+    for (uint32_t u = 0; u < n; u++) dirty[u] = u;
+    while (!dirty.empty()) {
+        std::sort(dirty.begin(), dirty.end(), [&](uint32_t x, uint32_t y) {
+            return block[x] != block[y] ? block[x] < block[y] : sum[x] != sum[y] ? sum[x] < sum[y] : x < y; });
         next_dirty.clear();
-        for (auto it = groups.begin(); it != groups.end();) {
-            const uint32_t B = it->first[0];
-            auto end = it;
-            const std::vector<uint32_t> *keep = nullptr;
-            size_t best = 0;
-            auto rp = reps.find(B);
-            for (; end != groups.end() && end->first[0] == B; ++end) {
-                if (rp != reps.end()) { if (end->first == rp->second.rep_sig) keep = &end->first; }
-                else if (end->second.size() > best) { best = end->second.size(); keep = &end->first; }
-            }
-            for (; it != end; ++it) {
-                if (keep && &it->first == keep) continue;
-                const uint32_t nbk = count++;
-                members.emplace_back();
-                for (uint32_t u : it->second) {
-                    std::vector<uint32_t> &mb = members[B];
-                    const uint32_t last = mb.back();
-                    mb[where[u]] = last; where[last] = where[u]; mb.pop_back();
-                    where[u] = (uint32_t)members[nbk].size(); members[nbk].push_back(u);
-                    block[u] = nbk;
-                    for (uint32_t d : dep[u]) if (!queued[d]) { queued[d] = 1; next_dirty.push_back(d); }
+        for (size_t i = 0; i < dirty.size();) {
+            const uint32_t B = block[dirty[i]];
+            size_t end = i;
+            while (end < dirty.size() && block[dirty[end]] == B) end++;
+            // which group keeps the id B: the one that agrees with the clean members (they all carry one signature: none of
+            // their neighbours moved), or, if every member is dirty, the largest group
+            int64_t keep_from = -1;
+            if (end - i < members[B].size()) {
+                uint32_t clean = UINT32_MAX;
+                for (uint32_t u : members[B]) if (!is_dirty[u]) { clean = u; break; }
+                keep_from = (int64_t)end;                           // (no dirty group stays, unless one matches)
+                for (size_t g = i; g < end; g++) if (sum[dirty[g]] == sum[clean]) { keep_from = (int64_t)g; break; }
+            } else {
+                size_t best = 0;
+                for (size_t g = i; g < end;) {
+                    size_t g2 = g + 1;
+                    while (g2 < end && sum[dirty[g2]] == sum[dirty[g]]) g2++;
+                    if (g2 - g > best) { best = g2 - g; keep_from = (int64_t)g; }
+                    g = g2;
                 }
             }
+            for (size_t g = i; g < end;) {
+                size_t g2 = g + 1;
+                while (g2 < end && sum[dirty[g2]] == sum[dirty[g]]) g2++;
+                if ((int64_t)g != keep_from) {
+                    const uint32_t nbk = count++;
+                    members.emplace_back();
+                    for (size_t q = g; q < g2; q++) {
+                        const uint32_t u = dirty[q];
+                        std::vector<uint32_t> &mb = members[B];
+                        const uint32_t last = mb.back();
+                        mb[where[u]] = last; where[last] = where[u]; mb.pop_back();
+                        where[u] = (uint32_t)members[nbk].size(); members[nbk].push_back(u);
+                        moved.push_back(u); moved_from.push_back(B); moved_to.push_back(nbk);
+                    }
+                }
+                g = g2;
+            }
+            i = end;
         }
+        // the moves take effect together, after every group of the round has been formed on the old partition
+        for (size_t q = 0; q < moved.size(); q++) {
+            block[moved[q]] = moved_to[q];
+            for (uint32_t d : dep[moved[q]]) {
+                bump(d, moved_from[q], -1);
+                bump(d, moved_to[q], +1);
+                if (!queued[d]) { queued[d] = 1; next_dirty.push_back(d); }
+            }
+        }
+        moved.clear(); moved_from.clear(); moved_to.clear();
         for (uint32_t u : dirty) is_dirty[u] = 0;
         dirty.swap(next_dirty);
         for (uint32_t u : dirty) { is_dirty[u] = 1; queued[u] = 0; }
+    }
+    // the check: within a block every member must carry the same SET of neighbour blocks (the sums only said so)
+    for (uint32_t b = 0; b < count; b++) {
+        const std::vector<uint32_t> &mb = members[b];
+        for (size_t k = 1; k < mb.size(); k++) {
+            const auto &x = cnt[mb[0]], &y = cnt[mb[k]];
+            bool same = x.size() == y.size();
+            for (size_t q = 0; same && q < x.size(); q++) same = x[q].first == y[q].first;
+            if (!same) return false;                               // a 64-bit collision: merge nothing (sound, and never seen)
+        }
     }
     if (count == n) return false;
     // renumber so that node 0's block is 0 and the rest keep first-occurrence order
@@ -437,6 +706,24 @@ Reduced reduce(const Trimmed &t) {
     }
     nodes[0].follow = follow_of_state[t.initial];
     for (uint32_t s = 0; s < t.n; s++) for (auto &kv : copies[s]) nodes[kv.second].follow = follow_of_state[s];
+    // ---- the dominated edges trim() dropped may have been the only way into some nodes
+    {
+        const uint32_t n = (uint32_t)nodes.size();
+        std::vector<int64_t> id(n, -1);
+        std::vector<uint32_t> reach{0};
+        id[0] = 0;
+        for (size_t k = 0; k < reach.size(); k++)
+            for (uint32_t v : nodes[reach[k]].follow) if (id[v] < 0) { id[v] = (int64_t)reach.size(); reach.push_back(v); }
+        if (reach.size() < n) {
+            std::vector<Node> kept(reach.size());
+            for (size_t k = 0; k < reach.size(); k++) {
+                kept[k] = std::move(nodes[reach[k]]);
+                for (uint32_t &v : kept[k].follow) v = (uint32_t)id[v];
+                sort_unique(kept[k].follow);
+            }
+            nodes.swap(kept);
+        }
+    }
     // ---- shrink
     for (int round = 0; round < 8; round++) {
         bool c = prune_by_containment(nodes);              // first: it cuts the edge count the quotients iterate over
@@ -542,7 +829,7 @@ bool lower_nfa(const Reduced &red, uint32_t max_bits, NfaProgram &p, bool allow_
 }
 
 // ------------------------------------------------------------------------------------------ DFA lowering
-// Subset construction + Moore minimisation.  `sticky`: the initial node stays in every set and no byte kills (the
+// Subset construction + minimisation.  `sticky`: the initial node stays in every set and no byte kills (the
 // automaton of "anything, then the pattern": search_dfas below); class 0 then gets a real column.
 static bool subset_construct(const Reduced &red, uint32_t max_states, bool sticky, DfaProgram &d) {
     d = DfaProgram();
@@ -573,12 +860,14 @@ static bool subset_construct(const Reduced &red, uint32_t max_states, bool stick
     };
     intern({});                                         // 0 = dead (unreachable when sticky)
     intern({0});                                        // 1 = start: the initial node
-    std::vector<uint32_t> all;
+    std::vector<uint32_t> all, seen_at(N, 0);
+    uint32_t epoch = 0;
     for (uint32_t cur = 0; cur < sets.size(); cur++) {
         nxt.resize((size_t)(cur + 1) * K, 0);
-        all.clear();
-        for (uint32_t u : sets[cur]) all.insert(all.end(), nodes[u].follow.begin(), nodes[u].follow.end());
-        sort_unique(all);
+        all.clear();                                    // the union of the follow sets: each node once, then sorted
+        epoch++;
+        for (uint32_t u : sets[cur]) for (uint32_t v : nodes[u].follow) if (seen_at[v] != epoch) { seen_at[v] = epoch; all.push_back(v); }
+        std::sort(all.begin(), all.end());
         for (uint32_t k = sticky ? 0 : 1; k < K; k++) {
             std::vector<uint32_t> v;
             if (sticky && cur != 0) v.push_back(0);     // node 0 sorts first; it is entered on nothing
@@ -591,36 +880,92 @@ static bool subset_construct(const Reduced &red, uint32_t max_states, bool stick
     const uint32_t D = (uint32_t)sets.size();
     std::vector<uint8_t> acc(D, 0);
     for (uint32_t i = 0; i < D; i++) for (uint32_t u : sets[i]) if (nodes[u].fin) { acc[i] = 1; break; }
-    // ---- Moore minimisation
+    // ---- minimisation: Hopcroft's partition refinement (the "recompute every signature until nothing splits" form took one
+    // round per state on a chain - a{1,n} is n rounds over n states: 0.45 s at n = 2400, minutes at 16000)
     std::vector<uint32_t> block(D);
-    for (uint32_t i = 0; i < D; i++) block[i] = acc[i];
-    uint32_t count = 2, prev;
+    uint32_t count = 0;
     {
-        bool any0 = false, any1 = false;
-        for (uint32_t i = 0; i < D; i++) (acc[i] ? any1 : any0) = true;
-        count = (any0 ? 1 : 0) + (any1 ? 1 : 0);
-    }
-    do {
-        prev = count;
-        std::map<std::vector<uint32_t>, uint32_t> sigs;
-        std::vector<uint32_t> nb(D);
-        for (uint32_t i = 0; i < D; i++) {
-            std::vector<uint32_t> sig(K + 1);
-            sig[0] = block[i];
-            for (uint32_t k = 1; k < K; k++) sig[k] = block[nxt[(size_t)i * K + k]];
-            sig[K] = block[nxt[(size_t)i * K]];         // class 0: the dead block unless sticky
-            auto it = sigs.find(sig);
-            if (it == sigs.end()) it = sigs.emplace(std::move(sig), (uint32_t)sigs.size()).first;
-            nb[i] = it->second;
+        // inverse transitions per class, CSR: inv[k][first[k][t] .. first[k][t + 1]) = the states that go to t on class k
+        std::vector<uint32_t> first((size_t)K * (D + 1), 0), inv((size_t)K * D);
+        for (uint32_t i = 0; i < D; i++) for (uint32_t k = 0; k < K; k++) first[(size_t)k * (D + 1) + nxt[(size_t)i * K + k] + 1]++;
+        for (uint32_t k = 0; k < K; k++) for (uint32_t t2 = 0; t2 < D; t2++) first[(size_t)k * (D + 1) + t2 + 1] += first[(size_t)k * (D + 1) + t2];
+        {
+            std::vector<uint32_t> fill(first);
+            for (uint32_t i = 0; i < D; i++)
+                for (uint32_t k = 0; k < K; k++) inv[(size_t)k * D + fill[(size_t)k * (D + 1) + nxt[(size_t)i * K + k]]++] = i;
         }
-        block.swap(nb);
-        count = (uint32_t)sigs.size();
-    } while (count != prev);
-    // renumber: dead block -> 0, then first-occurrence order
+        // the partition: elems holds the states block by block; a block is elems[lo[b] .. hi[b])
+        std::vector<uint32_t> elems(D), loc(D), lo, hi, marked;
+        {
+            uint32_t n0 = 0;
+            for (uint32_t i = 0; i < D; i++) if (!acc[i]) n0++;
+            uint32_t p0 = 0, p1 = n0;
+            for (uint32_t i = 0; i < D; i++) { const uint32_t at = acc[i] ? p1++ : p0++; elems[at] = i; loc[i] = at; }
+            if (n0) { lo.push_back(0); hi.push_back(n0); }
+            if (n0 < D) { lo.push_back(n0); hi.push_back(D); }
+            for (uint32_t b = 0; b < lo.size(); b++) for (uint32_t q = lo[b]; q < hi[b]; q++) block[elems[q]] = b;
+        }
+        marked.assign(lo.size(), 0);
+        std::vector<uint8_t> queued;                    // [block][class]
+        std::vector<std::pair<uint32_t, uint32_t>> work;
+        auto enqueue = [&](uint32_t b, uint32_t k) {
+            if (queued.size() < (size_t)(b + 1) * K) queued.resize((size_t)(b + 1) * K, 0);
+            if (!queued[(size_t)b * K + k]) { queued[(size_t)b * K + k] = 1; work.emplace_back(b, k); }
+        };
+        {
+            const uint32_t small = lo.size() == 2 && hi[1] - lo[1] < hi[0] - lo[0] ? 1 : 0;
+            if (lo.size() == 2) for (uint32_t k = 0; k < K; k++) enqueue(small, k);
+        }
+        std::vector<uint32_t> touched, splitter;
+        while (!work.empty()) {
+            const uint32_t B = work.back().first, k = work.back().second;
+            work.pop_back();
+            queued[(size_t)B * K + k] = 0;
+            splitter.assign(elems.begin() + lo[B], elems.begin() + hi[B]);      // (B itself may split below)
+            touched.clear();
+            for (uint32_t t2 : splitter)
+                for (uint32_t q = first[(size_t)k * (D + 1) + t2]; q < first[(size_t)k * (D + 1) + t2 + 1]; q++) {
+                    const uint32_t i = inv[(size_t)k * D + q], b = block[i];
+                    const uint32_t at = loc[i], to = lo[b] + marked[b];          // move i into the marked prefix of its block
+                    if (at < to) continue;                                       // (already marked)
+                    const uint32_t other = elems[to];
+                    elems[to] = i; loc[i] = to; elems[at] = other; loc[other] = at;
+                    if (!marked[b]++) touched.push_back(b);
+                }
+            for (uint32_t b : touched) {
+                const uint32_t m = marked[b];
+                marked[b] = 0;
+                if (m == hi[b] - lo[b]) continue;                                // the whole block goes there: no split
+                const uint32_t nb = (uint32_t)lo.size();                         // the marked prefix becomes block nb
+                lo.push_back(lo[b]); hi.push_back(lo[b] + m); marked.push_back(0);
+                lo[b] += m;
+                for (uint32_t q = lo[nb]; q < hi[nb]; q++) block[elems[q]] = nb;
+                const bool nb_smaller = hi[nb] - lo[nb] <= hi[b] - lo[b];
+                for (uint32_t c = 0; c < K; c++) {
+                    if (queued.size() >= (size_t)(b + 1) * K && queued[(size_t)b * K + c]) enqueue(nb, c);
+                    else enqueue(nb_smaller ? nb : b, c);
+                }
+            }
+        }
+        count = (uint32_t)lo.size();
+    }
+    // renumber: the dead block -> 0, the others in breadth-first order from the start state, classes ascending - a numbering
+    // that depends on the language and its byte classes only, not on which equivalent automaton the subset construction saw
     std::vector<int64_t> id(count, -1);
     uint32_t next_id = 0;
     id[block[0]] = next_id++;
-    for (uint32_t i = 0; i < D; i++) if (id[block[i]] < 0) id[block[i]] = next_id++;
+    {
+        std::vector<uint32_t> rep(count, UINT32_MAX), bfs;
+        for (uint32_t i = 0; i < D; i++) if (rep[block[i]] == UINT32_MAX) rep[block[i]] = i;
+        if (id[block[1]] < 0) id[block[1]] = next_id++;
+        bfs.push_back(block[1]);
+        for (size_t h = 0; h < bfs.size(); h++)
+            for (uint32_t k = 0; k < K; k++) {
+                const uint32_t nb = block[nxt[(size_t)rep[bfs[h]] * K + k]];
+                if (id[nb] < 0) { id[nb] = next_id++; bfs.push_back(nb); }
+            }
+        for (uint32_t b = 0; b < count; b++) if (id[b] < 0) id[b] = next_id++;    // (none: every set is reachable)
+    }
     if (count > 65535) return false;
     d.nstates = count;
     d.accepting.assign(count, 0);

@@ -32,7 +32,8 @@ struct Trimmed {
     uint32_t n = 0;                         // 0 => empty language
     uint32_t initial = 0;
     std::vector<uint8_t> is_final;
-    std::vector<std::vector<Edge>> out;     // labels never contain NUL (it cannot occur inside a string)
+    std::vector<std::vector<Edge>> out;     // labels never contain NUL (it cannot occur inside a string); dominated edges
+                                            //   dropped (lower.cpp: trim) - every state keeps its language
     std::vector<uint32_t> ref_id;           // state id in the reference numbering
     uint32_t ncls = 1;                      // byte classes; class 0 = bytes on which nothing moves
     uint8_t cls[256];                       // byte -> class (0x00 and >= 0x80 are class 0)
@@ -40,6 +41,9 @@ struct Trimmed {
 };
 
 Trimmed trim(const RefAutomaton &a);
+constexpr uint64_t kTrimPairTests = (uint64_t)1 << 25;      // edge pairs the domination proofs may compare; then only the structural rule
+constexpr uint64_t kTrimBudget = (uint64_t)1 << 21;          // edges the pruned rows may hold in all (then: BudgetError): the passes
+                                                             //   behind trim cost 2-3 us per edge, so this is a few seconds
 
 constexpr uint32_t kDenseExceptionBits = 4096;
 
