@@ -79,9 +79,11 @@ struct PieceTrimmer {
     // repeated operand: (a+b+){1,n} needs "the a-loop of copy i over the a-loop of copy j" to prove itself).  A success that
     // leans on a pair still in progress further up is only as good as that pair: it is handed up (`leans`), never cached;
     // successes that lean on nothing outside their own proof, and all failures (an assumption can only help), are cached.
-    std::unordered_map<uint64_t, uint8_t> memo;                 // (v, w, depth) -> 1 no / 2 yes
+    std::unordered_map<uint64_t, uint8_t> memo;                 // (v, w) -> 2 yes / 1 no / 16 + d: no within depth d
     std::vector<std::pair<uint32_t, uint32_t>> in_progress;
-    bool dominates(uint32_t v, uint32_t w, int depth, uint32_t &leans) {       // L(v) >= L(w), proven
+    static constexpr int kProofDepth = 48;                      // (abcdefghij){1,n}: one level per state of the operand
+    // `cut`: set when a limit (depth, an unfinished row, the size caps) stood in for a real "no" somewhere in the proof
+    bool dominates(uint32_t v, uint32_t w, int depth, uint32_t &leans, bool &cut) {       // L(v) >= L(w), proven
         leans = UINT32_MAX;
         if (a.is_final[w] && !a.is_final[v]) return false;
         const uint32_t hw = a.head[w], hv = a.head[v];
@@ -89,18 +91,22 @@ struct PieceTrimmer {
         if (st[hw] == 2 && pe[hw].empty()) return true;
         if (hv == kNoPiece) return false;
         if (is_descendant(hv, hw)) return true;
-        if (depth == 0 || st[hv] != 2 || st[hw] != 2 || pair_tests > kTrimPairTests) return false;
+        if (depth == 0 || st[hv] != 2 || st[hw] != 2 || pair_tests > kTrimPairTests) { cut = true; return false; }
         if (!subset(first[hw], first[hv])) return false;           // w can start with a character v cannot
         for (uint32_t i = 0; i < in_progress.size(); i++) if (in_progress[i].first == v && in_progress[i].second == w) { leans = i; return true; }
         const std::vector<Edge> &rv = pe[hv], &rw = pe[hw];
-        if (rw.size() * rv.size() > 64) return false;
-        const uint64_t key = ((uint64_t)v << 34) | ((uint64_t)w << 4) | (uint64_t)depth;
+        if (rw.size() * rv.size() > 1024) { cut = true; return false; }
+        const uint64_t key = ((uint64_t)v << 32) | w;
         auto it = memo.find(key);
-        if (it != memo.end()) return it->second == 2;
+        if (it != memo.end()) {
+            if (it->second == 2) return true;
+            if (it->second == 1) return false;
+            if (it->second - 16 >= depth) { cut = true; return false; }
+        }
         pair_tests += rw.size() * rv.size();
         const uint32_t me = (uint32_t)in_progress.size();
         in_progress.emplace_back(v, w);
-        bool all = true;
+        bool all = true, my_cut = false;
         uint32_t lowest = UINT32_MAX;
         for (const Edge &e : rw) {
             bool found = false;
@@ -108,13 +114,17 @@ struct PieceTrimmer {
                 if (!subset(e.on, f.on)) continue;
                 if (f.to == e.to) { found = true; break; }
                 uint32_t l;
-                if (dominates(f.to, e.to, depth - 1, l)) { lowest = std::min(lowest, l); found = true; break; }
+                if (dominates(f.to, e.to, depth - 1, l, my_cut)) { lowest = std::min(lowest, l); found = true; break; }
             }
             if (!found) { all = false; break; }
         }
         in_progress.pop_back();
-        if (!all) { memo.emplace(key, 1); return false; }
-        if (lowest >= me) memo.emplace(key, 2);                 // leans on itself at most
+        if (!all) {
+            memo[key] = my_cut ? (uint8_t)(16 + depth) : (uint8_t)1;
+            cut = cut || my_cut;
+            return false;
+        }
+        if (lowest >= me) memo[key] = 2;                        // leans on itself at most
         else leans = lowest;
         return true;
     }
@@ -174,7 +184,8 @@ struct PieceTrimmer {
                     if (from[v] == from[w] && from[v] != 0 && from[v] != 0xffff) continue;      // compared when that child was built
                     if (++tried > per_edge) break;
                     uint32_t leans;
-                    if (dominates(merged[v].to, merged[w].to, 6, leans)) { dropped[w] = 1; break; }
+                    bool cut = false;
+                    if (dominates(merged[v].to, merged[w].to, kProofDepth, leans, cut)) { dropped[w] = 1; break; }
                 }
             }
         }

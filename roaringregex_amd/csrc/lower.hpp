@@ -41,7 +41,7 @@ struct Trimmed {
 };
 
 Trimmed trim(const RefAutomaton &a);
-constexpr uint64_t kTrimPairTests = (uint64_t)1 << 25;      // edge pairs the domination proofs may compare; then only the structural rule
+constexpr uint64_t kTrimPairTests = (uint64_t)1 << 23;      // edge pairs the domination proofs may compare; then only the structural rule
 constexpr uint64_t kTrimBudget = (uint64_t)1 << 21;          // edges the pruned rows may hold in all (then: BudgetError): the passes
                                                              //   behind trim cost 2-3 us per edge, so this is a few seconds
 

@@ -385,3 +385,139 @@ def test_search_tables_find_the_earliest_ending_leftmost_match():
             want = [(int(ast[k + j]), int(aen[k + j])) for j in range(int(c))]
             assert rep.search_all(ln) == want, (p[:50], ln, want)
             k += int(c)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Large bounded repeats: the reference builds x{m,n} by plain copies and resolves every eps-edge of the fold
+# eagerly (Parser.cpp:123-141, NFA.cc:108-121, 172-185): n^2/2 edges.  The front end keeps rows as shared pieces, trim() drops the
+# dominated skip edges from the pieces; both must stay exact.
+
+def nullable_heavy_pattern(rng, depth=0):
+    """Random patterns dense in what makes the fold quadratic: optional / starred / {0,n} / {1,n} operands, nested."""
+    parts = []
+    for _ in range(rng.randint(1, 3 if depth else 4)):
+        r = rng.random()
+        if depth < 3 and r < 0.45:
+            alts = [nullable_heavy_pattern(rng, depth + 1) for _ in range(rng.randint(1, 2))]
+            atom = "(" + "|".join(alts) + ")"
+        else:
+            atom = rng.choice(["a", "b", "c", "[ab]", "[bc]", "."])
+        q = rng.random()
+        if q < 0.20:
+            atom += "?"
+        elif q < 0.32:
+            atom += "*"
+        elif q < 0.40:
+            atom += "+"
+        elif q < 0.62:
+            atom += "{%d,%d}" % (rng.randint(0, 1), rng.randint(2, 7))
+        elif q < 0.70:
+            atom += "{%d}" % rng.randint(2, 4)
+        parts.append(atom)
+    return "".join(parts)
+
+
+def test_nested_nullable_repeats_build_the_reference_table():
+    rng = random.Random(77)
+    n_ok = 0
+    for _ in range(400):
+        p = nullable_heavy_pattern(rng)
+        try:
+            o = OracleRegex(p)
+        except OracleError:
+            continue
+        if o.states_n > 700:
+            continue
+        r = rr.RRegex(p)
+        _same_table(o, r, sample=None if o.states_n <= 250 else [0, 1, o.states_n - 1] + [rng.randrange(o.states_n) for _ in range(60)])
+        for rep in _replays(r):
+            for t in strings_near(rng, o, alphabet="abc", tries=30, maxlen=16):
+                assert rep.accepts(t.encode()) == o.accepts(t), (p, t, type(rep).__name__)
+        n_ok += 1
+    assert n_ok > 250
+
+
+@pytest.mark.parametrize("p,alphabet", [
+    ("(ab){1,40}", "ab"), ("(abc|de){1,25}", "abcde"), ("(a+b+){1,12}", "ab"), ("(a{0,3}b{0,3}){1,9}", "ab"),
+    ("([ab]{1,10}c?){1,8}", "abc"), ("(a{1,9}){1,9}", "a"), ("(abcdefghij){1,9}", "abcdefghij"), ("((ab){1,5}c){1,6}x?", "abcx"),
+    ("(a?b?c?){1,12}", "abc"), ("((a|b)*a(a|b){3}){1,10}", "ab"), ("(k1|k2|k10|k11|k12){1,6}", "k012"), ("(a*b*){1,7}x", "abx"),
+    ("(a?|b?c)*{1,9}", "abc"), ("((a|b)?(c|d)?){1,11}x", "abcdx"), ("(.?a){1,9}", "ab"), ("(a|bc?)+{1,6}", "abc")])
+def test_repeat_families_keep_the_language(p, alphabet):
+    """The families the domination proofs of trim() are made for, at sizes the oracle finishes: every device program accepts
+    exactly what the oracle accepts, on random strings, mutations of accepted ones and long runs."""
+    rng = random.Random(len(p) * 7919)
+    o = OracleRegex(p)
+    r = rr.RRegex(p)
+    reps = _replays(r)
+    for e in (rr.ENGINE_NFA_WAVE, rr.ENGINE_NFA_BLOCK):
+        reps.append(NfaReplay(rr.RRegex(p, e).program(e), sparse=(e == rr.ENGINE_NFA_BLOCK)))
+    texts = strings_near(rng, o, alphabet=alphabet, tries=120, maxlen=30)
+    texts += ["".join(rng.choice(alphabet) for _ in range(rng.randint(20, 120))) for _ in range(40)]
+    texts += [(alphabet[:k] * 200)[:n] for k in (1, 2, len(alphabet)) for n in (17, 18, 19, 20, 40, 80, 81, 90, 91, 120)]
+    if p.startswith("(k1|"):
+        kws = ["k1", "k2", "k10", "k11", "k12"]
+        texts += ["".join(rng.choice(kws) for _ in range(n)) for n in (1, 2, 3, 5, 6, 7, 8) for _ in range(4)]
+    seen_accept = False
+    for t in texts:
+        want = o.accepts(t)
+        seen_accept = seen_accept or want
+        for rep in reps:
+            assert rep.accepts(t.encode()) == want, (p, t, type(rep).__name__)
+    assert seen_accept
+
+
+def test_compile_time_of_large_repeats_is_bounded():
+    """Every pattern the front end admits compiles in seconds (the round-3 pipeline: a{1,9600} 126 s, (ab){1,2400} 289 s)."""
+    import time
+    cases = [("a{1,20000}", 20001), ("[ab]{1,20000}", 20001), ("(ab){1,5000}", 10001), ("(abc|de){1,3000}", 12002),
+             ("(a+b+){1,5000}", 20001), ("(abcdefghij){1,3000}", 30001), ("(a{0,3}b{0,3}){1,1500}", 12001), ("(a{1,100}){1,100}", 10001),
+             ("([ab]{1,40}c?){1,200}", 8201), ("(a?){20000}", 20001), ("((a|b)*a(a|b){10}c?){1,1000}", 13001)]
+    for p, useful in cases:
+        t0 = time.time()
+        r = rr.RRegex(p)
+        dt = time.time() - t0
+        assert dt < 5.0, (p, dt)
+        assert r.useful_states == useful, (p, r.useful_states)
+    # closed form: a{1,20000} accepts a^n for 1 <= n <= 20000 and nothing else
+    r = rr.RRegex("a{1,20000}")
+    assert r.states_n == 59999 and r.engine_name == "nfa-wave-resident"
+    rep = NfaReplay(r.program(rr.ENGINE_NFA_BLOCK), sparse=True)
+    for n, want in ((0, False), (1, True), (2, True), (19999, True), (20000, True), (20001, False), (20500, False)):
+        assert rep.accepts(b"a" * n) == want, n
+    assert not rep.accepts(b"a" * 700 + b"b" + b"a" * 700)
+    # the expanded rows are the reference's (the n^2/2 edges, on demand): the second copy's initial state reaches the state
+    # behind `a` and the initial state of every later copy, the one after it two fewer (a{1,6}: [3,5,6,8,...,15], [6,8,...,15])
+    assert r.row(0, ord("a")) == [1, 2] and not r.row(0, ord("b")) and not r.row(1, ord("a"))
+    row = r.row(2, ord("a"))
+    assert len(row) == 39997 and row[:6] == [3, 5, 6, 8, 9, 11] and row[-1] == 59997
+    assert r.row(5, ord("a")) == row[2:]
+    # (ab){1,5000} determinises into a chain: exactly the table a hand-written matcher would use
+    r = rr.RRegex("(ab){1,5000}")
+    rep = DfaReplay(r.program(rr.ENGINE_DFA))
+    for n in (0, 1, 2, 4999, 5000, 5001):
+        assert rep.accepts(b"ab" * n) == (1 <= n <= 5000), n
+    assert not rep.accepts(b"ab" * 10 + b"a")
+
+
+def test_budget_refusal_is_an_error_not_a_hang():
+    """What the pipeline will not build within its work budget is refused with RRX_ERR_UNSUPPORTED in seconds.  A sequence of n
+    DIFFERENT optional keywords needs its n^2/2 skip edges (no copy stands in for another): 1500 of them compile, 2600 exceed
+    the edge budget (lower.hpp: kTrimBudget)."""
+    import ctypes as C
+    import time
+    L = rr._L
+    ok = "".join("(k%d)?" % i for i in range(1, 1501))
+    t0 = time.time()
+    r = rr.RRegex(ok)
+    assert time.time() - t0 < 5.0 and r.states_n == 14286
+    rep = DfaReplay(r.program(rr.ENGINE_DFA))
+    for t, want in (("", True), ("k1", True), ("k1k2", True), ("k2k1", False), ("k7k900k1500", True), ("k1500k1", False), ("k15", True), ("k1501", False)):
+        assert rep.accepts(t.encode()) == want, t
+    big = "".join("(k%d)?" % i for i in range(1, 2601))
+    h = C.c_void_p()
+    t0 = time.time()
+    rc = L.rrx_compile(big.encode(), C.byref(h))
+    assert rc == 4 and time.time() - t0 < 5.0                      # RRX_ERR_UNSUPPORTED
+    assert b"work budget" in L.rrx_last_error()
+    with pytest.raises(rr.RRegexError, match="too many states"):   # RRX_ERR_PATTERN: beyond the front end's 65536 states
+        rr.RRegex("(a|b)*a(a|b){20000}")

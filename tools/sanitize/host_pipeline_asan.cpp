@@ -31,7 +31,11 @@ int main() {
         "abc", "a*", "(ab)+", "a{1,85}", "a{1,300}", "(a|b)*a(a|b){40}", "(a|b)*a(a|b){600}", "(a|b)*a(a|b){3000}", "(a|b)*a.{6000}",
         "[A-Za-z0-9._]+@[A-Za-z0-9.]+",
         "(http|https|ftp)://([a-z0-9-]{1,16}\\.){1,3}[a-z]{2,6}(:[0-9]{1,5})?(/[A-Za-z0-9._~%-]*)*(\\?[A-Za-z0-9._~%=&-]*)?(#[A-Za-z0-9._~%-]*)?",
-        "((a|b)*a(a|b){700}c|(b|c)*b(b|c){800}a)*", "(ab|ba){1,120}", "b*a{1,440}", "x?y?z?", "(a*b)*"};
+        "((a|b)*a(a|b){700}c|(b|c)*b(b|c){800}a)*", "(ab|ba){1,120}", "b*a{1,440}", "x?y?z?", "(a*b)*",
+        // nullable folds the front end keeps as shared row pieces, and what the domination proofs of trim() meet in them
+        "a{1,20000}", "[ab]{1,9000}", "(ab){1,5000}", "(abc|de){1,3000}", "(a+b+){1,1500}", "(a{0,3}b{0,3}){1,400}", "([ab]{1,40}c?){1,60}",
+        "(a{1,40}){1,40}", "(abcdefghij){1,900}", "((ab){1,20}c){1,30}", "(a?b?c?){1,700}", "((a|b)*c?){1,500}", "(a?|b?c)*{1,300}",
+        "((a|b)*a(a|b){5}){1,200}", "(a*b*){1,500}x", "(a?){3000}"};
     std::string kw;
     for (int i = 1; i <= 300; i++) kw += (i > 1 ? "|k" : "k") + std::to_string(i);
     pats.push_back(kw);
