@@ -59,8 +59,9 @@ uint32_t    rrx_byte_classes(const rrx_regex *re);
 /* 1 if the stride-2 table of this regex is laid out in a PROFILED order, 2 while the search for one is running, else 0.  At a
  * regex' first rrx_match_corpus against a corpus of 64 MiB or more a background thread (tens of ms of host work, once per
  * regex; tables small enough to be replicated are left alone) orders the rows and columns of the table by a 64 KiB sample of
- * that corpus' text so that fewer of a half-wave's lookups fall into one LDS bank, and swaps the tables in when it is done:
- * no call waits for it, launches before the swap run on the table as numbered.  *before / *after: the mean
+ * that corpus' text so that fewer of a half-wave's lookups fall into one LDS bank, uploads the table again in that order
+ * (its own hipMalloc + copies, no lock held) and swaps the descriptors in under the regex' mutex, which launches take for the
+ * length of a copy: launches before the swap run on the table as numbered.  rrx_set_option can forbid it.  *before / *after: the mean
  * number of distinct entries in the fullest bank per half-wave on that sample (either may be NULL).  Results never depend
  * on the order.                                                                                                        */
 int         rrx_table_order(const rrx_regex *re, double *conflict_before, double *conflict_after);
@@ -68,6 +69,12 @@ int         rrx_table_order(const rrx_regex *re, double *conflict_before, double
  * 32) pieces of `bytes_per_lane` bytes each, lane-major - 32 consecutive pieces are stepped in lockstep the way a half-wave
  * steps 32 neighbouring stripes, so take them from 32 places of the text a stripe (some KiB) apart.  Host only.              */
 int         rrx_order_table(rrx_regex *re, const void *sample, uint32_t lanes, uint32_t bytes_per_lane);
+/* Per-regex options.  RRX_OPT_BACKGROUND_ORDER (default 1): 0 forbids the library to start a thread of its own and to
+ * allocate device memory behind the caller's back for the profiled table order above - the table then stays as numbered
+ * unless the caller orders it himself with rrx_order_table (which runs in the calling thread).  Set it before the regex'
+ * first rrx_match_corpus; a search that is already running is not stopped.  RRX_ERR_ARG for an unknown option.          */
+enum { RRX_OPT_BACKGROUND_ORDER = 1 };
+int         rrx_set_option(rrx_regex *re, int option, int64_t value);
 uint32_t    rrx_words_per_set(const rrx_regex *re); /* 32-bit words of the register-resident state set (NFA) */
 int         rrx_accepts_empty(const rrx_regex *re); /* Processor::operator*() on the initial set, NFA.cc:103-107 */
 /* Serialised device program as 32-bit words (layout: DESIGN.md "Device programs"); returns the word count

@@ -19,12 +19,13 @@ ENGINE_NFA_BLOCK = 8
 ENGINE_NFA_SPARSE = 10
 PROGRAM_SEARCH_LINE = 9
 PROGRAM_DFA2_ORDER = 11
+OPT_BACKGROUND_ORDER = 1
 
 # every symbol include/rrx.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = (
     "rrx_compile", "rrx_compile_ex", "rrx_free", "rrx_last_error",
     "rrx_num_states", "rrx_set_class", "rrx_ref_initial", "rrx_ref_is_final", "rrx_ref_row",
-    "rrx_engine", "rrx_engine_name", "rrx_useful_states", "rrx_byte_classes", "rrx_table_order", "rrx_order_table", "rrx_words_per_set", "rrx_accepts_empty",
+    "rrx_engine", "rrx_engine_name", "rrx_useful_states", "rrx_byte_classes", "rrx_table_order", "rrx_order_table", "rrx_set_option", "rrx_words_per_set", "rrx_accepts_empty",
     "rrx_program_words",
     "rrx_corpus_create", "rrx_corpus_create_ex", "rrx_corpus_stripe_bytes", "rrx_corpus_num_lines", "rrx_corpus_num_bytes", "rrx_corpus_free", "rrx_corpus_bitmap_words",
     "rrx_match_corpus", "rrx_match_device", "rrx_search_corpus", "rrx_search_all_count", "rrx_search_all_fill", "rrx_search_all", "rrx_bitmap_to_bytes",
@@ -66,6 +67,7 @@ def _load():
         "rrx_useful_states": (u32, [vp]),
         "rrx_byte_classes": (u32, [vp]),
         "rrx_table_order": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "rrx_set_option": (i32, [vp, i32, C.c_int64]),
         "rrx_order_table": (i32, [vp, vp, u32, u32]),
         "rrx_words_per_set": (u32, [vp]),
         "rrx_accepts_empty": (i32, [vp]),
@@ -447,6 +449,11 @@ class RRegex:
         assert a.size >= lanes * bytes_per_lane
         _check(_L.rrx_order_table(self._h, C.c_void_p(a.ctypes.data), lanes, bytes_per_lane))
         return self.table_order
+
+    def set_background_order(self, enabled):
+        """rrx_set_option(RRX_OPT_BACKGROUND_ORDER): False forbids the library's own thread and device allocations for the profiled
+        table order (the table stays as numbered unless order_table is called)."""
+        _check(_L.rrx_set_option(self._h, OPT_BACKGROUND_ORDER, 1 if enabled else 0))
 
     @property
     def table_order(self):

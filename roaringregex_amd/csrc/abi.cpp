@@ -109,22 +109,25 @@ struct rrx_regex {
     // Order of the stride-2 table's rows and columns in LDS (empty: as numbered).  The order costs no memory and decides which
     // entries share an LDS bank: bank = (row slot * row words + column slot) mod 32.  State 0 (dead) keeps slot 0.
     std::vector<uint32_t> t2_row_slot, t2_col_slot;
-    mutable std::atomic<bool> t2_order_decided{false}, t2_order_done{false};
-    mutable Dfa2OrderStats t2_order_stats;
-    mutable std::thread t2_order_thread;                 // the background order search (joined by the destructor)
+    mutable TableOrderSearch t2_order;                   // the order search, in the background or in the caller of rrx_order_table
+    mutable Dfa2OrderStats t2_order_stats;               // (under `mu`)
+    std::atomic<int> opt_background_order{1};            // RRX_OPT_BACKGROUND_ORDER
     mutable std::vector<std::pair<int, void *>> t2_extra_blobs;      // tables uploaded again in the profiled order (device, blob)
     // The stride-2 tables as they go to the device, in the current order: T2 rows of `ncols | 1` entries (odd), R interleaved
     // copies, entry = LDS byte offset of the next row | lines << 16 | verdicts << 24; P = pair -> byte offset of its column.
-    void build_dfa2_arrays(std::vector<uint32_t> &T2, std::vector<uint16_t> &P, dev::Dfa2Device &d) const {      // call with `mu` held
+    // `rows` / `cols`: an order to build for (else the current one: call with `mu` held)
+    void build_dfa2_arrays(std::vector<uint32_t> &T2, std::vector<uint16_t> &P, dev::Dfa2Device &d, const std::vector<uint32_t> *rows = nullptr,
+                           const std::vector<uint32_t> *cols = nullptr) const {
         const uint32_t D2 = dfa2.nstates, C2 = dfa2.ncols;
         const uint32_t s2 = C2 | 1u;
         uint32_t rep2 = 0;
         while (rep2 < 5 && (size_t)D2 * s2 * 4 * (2u << rep2) <= dev::kDfa2TableBudget && (size_t)C2 * 4 * (2u << rep2) <= 65535) rep2++;
         const uint32_t R2 = 1u << rep2;
         T2.assign((size_t)D2 * s2 * R2, 0);
-        const bool ordered = t2_row_slot.size() == D2 && t2_col_slot.size() == C2 && t2_row_slot[0] == 0;
-        auto row_slot = [&](uint32_t st) { return ordered ? t2_row_slot[st] : st; };
-        auto col_slot = [&](uint32_t col) { return ordered ? t2_col_slot[col] : col; };
+        const std::vector<uint32_t> &rs = rows ? *rows : t2_row_slot, &cs = cols ? *cols : t2_col_slot;
+        const bool ordered = rs.size() == D2 && cs.size() == C2 && rs[0] == 0;
+        auto row_slot = [&](uint32_t st) { return ordered ? rs[st] : st; };
+        auto col_slot = [&](uint32_t col) { return ordered ? cs[col] : col; };
         for (uint32_t st = 0; st < D2; st++)
             for (uint32_t col = 0; col < C2; col++) {
                 const uint32_t v = dfa2.next2[(size_t)st * C2 + col];
@@ -139,20 +142,23 @@ struct rrx_regex {
     bool t2_order_applies() const {                      // single-copy tables only: interleaved copies already keep lanes apart
         return has_dfa2 && (size_t)dfa2.nstates * (dfa2.ncols | 1u) * 4 * 2 > dev::kDfa2TableBudget;
     }
-    // The order search itself (tens of ms of host work) and, for devices whose tables are already up, a second upload of the
-    // stride-2 arrays in the new order; launches pick the descriptor up under `mu` (dfa2_device), so they see either set whole.
-    void run_t2_order(std::vector<uint8_t> sample, uint32_t lanes, uint32_t bytes_per_lane) const {
-        std::vector<uint32_t> rows, cols;
-        const Dfa2OrderStats st = order_dfa2(dfa2, sample.data(), lanes, bytes_per_lane, rows, cols);
-        std::lock_guard<std::mutex> lock(mu);
-        rrx_regex *self = const_cast<rrx_regex *>(this);
-        self->t2_row_slot.swap(rows); self->t2_col_slot.swap(cols);
-        t2_order_stats = st;
-        for (auto &kv : on_device) {
+    // What happens to a found order (runs in the searching thread).  For devices whose tables are already up the stride-2 arrays
+    // are built and uploaded again WITHOUT `mu` - launches go on meanwhile on the table as numbered; `mu` is taken twice, briefly:
+    // to read which devices are up, and to swap the slot vectors and the descriptors.  A device that comes up in between gets the
+    // numbered order and keeps it (its own arrays agree with each other; results never depend on the order).
+    void apply_t2_order(std::vector<uint32_t> &&rows, std::vector<uint32_t> &&cols, const Dfa2OrderStats &st) const {
+        std::vector<std::pair<int, dev::Dfa2Device>> up;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            for (auto &kv : on_device) up.emplace_back(kv.first, kv.second.dfa2);
+        }
+        struct Uploaded { int device; void *blob; dev::Dfa2Device d; };
+        std::vector<Uploaded> done;
+        for (auto &kv : up) {
             std::vector<uint32_t> T2;
             std::vector<uint16_t> P;
-            dev::Dfa2Device d = kv.second.dfa2;
-            build_dfa2_arrays(T2, P, d);
+            dev::Dfa2Device d = kv.second;
+            build_dfa2_arrays(T2, P, d, &rows, &cols);
             const size_t pb = (P.size() * 2 + 15) & ~(size_t)15;
             void *blob = nullptr;
             hipStream_t st2 = nullptr;
@@ -163,24 +169,31 @@ struct rrx_regex {
                          hipStreamSynchronize(st2) == hipSuccess;
             if (st2) (void)hipStreamDestroy(st2);
             if (!ok) { (void)hipGetLastError(); if (blob) (void)hipFree(blob); continue; }       // (that device keeps the numbered order)
-            t2_extra_blobs.emplace_back(kv.first, blob);
             d.P = static_cast<const uint16_t *>(blob);
             d.T2 = reinterpret_cast<const uint32_t *>(static_cast<uint8_t *>(blob) + pb);
-            kv.second.dfa2 = d;
+            done.push_back(Uploaded{kv.first, blob, d});
         }
-        t2_order_done = true;
+        std::lock_guard<std::mutex> lock(mu);
+        rrx_regex *self = const_cast<rrx_regex *>(this);
+        self->t2_row_slot.swap(rows); self->t2_col_slot.swap(cols);
+        t2_order_stats = st;
+        for (const Uploaded &u : done) {
+            t2_extra_blobs.emplace_back(u.device, u.blob);
+            auto it = on_device.find(u.device);
+            if (it != on_device.end()) it->second.dfa2 = u.d;
+        }
     }
     // First match against a corpus that carries a text sample: start the search in the background (the match itself, and the
-    // next ones, run on the table as numbered until the new order is in).  `now`: run it in the caller's thread (rrx_order_table).
-    void decide_t2_order(const uint8_t *sample, uint32_t lanes, uint32_t bytes_per_lane, bool now) const {
-        {
-            std::lock_guard<std::mutex> lock(mu);
-            if (t2_order_decided.exchange(true)) return;
-            if (!t2_order_applies() || !sample || lanes < 32) return;
-        }
+    // next ones, run on the table as numbered until the new order is in) - unless the caller has forbidden library threads
+    // (RRX_OPT_BACKGROUND_ORDER 0): then nothing happens here and rrx_order_table is the only way to an ordered table.
+    // `now`: run it in the caller's thread (rrx_order_table).  Returns false if the order had been decided before.
+    bool decide_t2_order(const uint8_t *sample, uint32_t lanes, uint32_t bytes_per_lane, bool now) const {
+        if (t2_order.decided()) return false;
+        if (!t2_order_applies() || !sample || lanes < 32) return t2_order.skip();
+        if (!now && !opt_background_order.load()) return true;                   // (left undecided: rrx_order_table may still come)
         std::vector<uint8_t> copy(sample, sample + (size_t)lanes * bytes_per_lane);
-        if (now) run_t2_order(std::move(copy), lanes, bytes_per_lane);
-        else t2_order_thread = std::thread([this, lanes, bytes_per_lane](std::vector<uint8_t> v) { run_t2_order(std::move(v), lanes, bytes_per_lane); }, std::move(copy));
+        return t2_order.start(dfa2, std::move(copy), lanes, bytes_per_lane, /*background=*/!now,
+                              [this](std::vector<uint32_t> &&r, std::vector<uint32_t> &&c, const Dfa2OrderStats &st) { apply_t2_order(std::move(r), std::move(c), st); });
     }
     dev::Dfa2Device dfa2_device(const DeviceTables *t) const { std::lock_guard<std::mutex> lock(mu); return t->dfa2; }
     int engine = 0;
@@ -249,7 +262,7 @@ struct rrx_regex {
     }
 
     ~rrx_regex() {
-        if (t2_order_thread.joinable()) t2_order_thread.join();
+        t2_order.wait();
         for (auto &kv : t2_extra_blobs) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second); }
         for (auto &kv : scratch) if (kv.second.p) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.p); }
         for (auto &kv : onepass_scratch) {
@@ -674,20 +687,22 @@ const char *rrx_engine_name(const rrx_regex *re) {
 uint32_t rrx_useful_states(const rrx_regex *re) { return re->trimmed.n; }
 int rrx_order_table(rrx_regex *re, const void *sample, uint32_t lanes, uint32_t bytes_per_lane) {
     if (!re || !sample || lanes < 32 || bytes_per_lane < 2) return fail(RRX_ERR_ARG, "sample: at least 32 lanes of 2 bytes");
-    {
-        std::lock_guard<std::mutex> lock(re->mu);
-        if (re->t2_order_decided) return fail(RRX_ERR_ARG, "the table order has been decided already");
-    }
-    re->decide_t2_order(static_cast<const uint8_t *>(sample), lanes, bytes_per_lane, /*now=*/true);
+    if (!re->decide_t2_order(static_cast<const uint8_t *>(sample), lanes, bytes_per_lane, /*now=*/true))
+        return fail(RRX_ERR_ARG, "the table order has been decided already");
     return RRX_OK;
 }
 int rrx_table_order(const rrx_regex *re, double *conflict_before, double *conflict_after) {
+    const TableOrderSearch::State st = re->t2_order.state();          // (one atomic read; the thread object is its owner's)
     std::lock_guard<std::mutex> lock(re->mu);
-    const bool profiled = re->t2_row_slot.size() == re->dfa2.nstates && re->has_dfa2 && re->t2_order_stats.half_waves;
+    const bool profiled = st == TableOrderSearch::kDone && re->t2_row_slot.size() == re->dfa2.nstates && re->has_dfa2 && re->t2_order_stats.half_waves;
     if (conflict_before) *conflict_before = profiled ? re->t2_order_stats.before : 0.0;
     if (conflict_after) *conflict_after = profiled ? re->t2_order_stats.after : 0.0;
-    if (profiled) return 1;
-    return re->t2_order_decided && !re->t2_order_done && re->t2_order_thread.joinable() ? 2 : 0;      // 2: the search is running
+    return profiled ? 1 : st == TableOrderSearch::kRunning ? 2 : 0;   // 2: the search is running
+}
+int rrx_set_option(rrx_regex *re, int option, int64_t value) {
+    if (!re) return fail(RRX_ERR_ARG, "null argument");
+    if (option == RRX_OPT_BACKGROUND_ORDER) { re->opt_background_order.store(value ? 1 : 0); return RRX_OK; }
+    return fail(RRX_ERR_ARG, "unknown option");
 }
 uint32_t rrx_byte_classes(const rrx_regex *re) { return re->trimmed.ncls; }
 uint32_t rrx_words_per_set(const rrx_regex *re) { return re->has_nfa ? re->nfa.W : re->has_wave ? re->nfa_wave.W : re->has_block ? re->nfa_block.W : 0; }
@@ -827,7 +842,7 @@ size_t rrx_corpus_bitmap_words(const rrx_corpus *c) { return (c->nlines + 31) / 
 
 int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accept_bits, void *stream) {
     if (!re || !c || (c->nlines && !d_accept_bits)) return fail(RRX_ERR_ARG, "null argument");
-    if (!re->t2_order_decided && c->h_sample && !c->has_high) re->decide_t2_order(c->h_sample, c->sample_lanes, kSampleBytes, /*now=*/false);
+    if (!re->t2_order.decided() && c->h_sample && !c->has_high) (void)re->decide_t2_order(c->h_sample, c->sample_lanes, kSampleBytes, /*now=*/false);
     const DeviceTables *t;
     int rc = re->tables(c->device, &t);
     if (rc) return rc;

@@ -1225,4 +1225,28 @@ Dfa2OrderStats order_dfa2(const Dfa2Program &d, const uint8_t *sample, uint32_t 
     return st;
 }
 
+// ------------------------------------------------------------------------------------------ the search beside the caller
+bool TableOrderSearch::start(const Dfa2Program &d, std::vector<uint8_t> sample, uint32_t lanes, uint32_t bytes_per_lane, bool background, Apply apply) {
+    std::unique_lock<std::mutex> lock(mu_);        // held from the decision to the thread being in place: wait() sees both or neither
+    int expected = kIdle;
+    if (!state_.compare_exchange_strong(expected, kRunning, std::memory_order_acq_rel)) return false;
+    auto body = [this, &d, lanes, bytes_per_lane](std::vector<uint8_t> text, Apply fn) {
+        std::vector<uint32_t> rows, cols;
+        const Dfa2OrderStats st = order_dfa2(d, text.data(), lanes, bytes_per_lane, rows, cols);
+        fn(std::move(rows), std::move(cols), st);
+        state_.store(kDone, std::memory_order_release);
+    };
+    if (!background) { lock.unlock(); body(std::move(sample), std::move(apply)); return true; }
+    thread_ = std::thread(body, std::move(sample), std::move(apply));
+    return true;
+}
+bool TableOrderSearch::skip() {
+    int expected = kIdle;
+    return state_.compare_exchange_strong(expected, kSkipped, std::memory_order_acq_rel);
+}
+void TableOrderSearch::wait() {
+    std::lock_guard<std::mutex> lock(mu_);
+    if (thread_.joinable()) thread_.join();
+}
+
 }  // namespace rrx

@@ -19,8 +19,12 @@
 // the accepted language of the reference automaton; tests/test_lowering.py replays the programs on the CPU
 // and compares with the oracle.
 #pragma once
+#include <atomic>
 #include <cstdint>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "frontend.hpp"
@@ -92,6 +96,31 @@ bool lower_dfa2(const DfaProgram &d, uint32_t max_cols, Dfa2Program &out);
 struct Dfa2OrderStats { double before = 0, after = 0; uint32_t half_waves = 0, evaluations = 0; };
 Dfa2OrderStats order_dfa2(const Dfa2Program &d, const uint8_t *sample, uint32_t lanes, uint32_t bytes_per_lane,
                           std::vector<uint32_t> &row_slot, std::vector<uint32_t> &col_slot);
+
+// The state machine around order_dfa2 when it runs beside the caller (host only: no device call in here; the owner passes what
+// to do with the result as `apply`).  One search per object, decided once: start() or skip() moves kIdle on, everything
+// else only READS the atomic state - the std::thread is touched by its owner alone (start under `mu_`, wait()).
+class TableOrderSearch {
+public:
+    enum State { kIdle = 0, kRunning = 1, kDone = 2, kSkipped = 3 };
+    using Apply = std::function<void(std::vector<uint32_t> &&row_slot, std::vector<uint32_t> &&col_slot, const Dfa2OrderStats &)>;
+    TableOrderSearch() = default;
+    TableOrderSearch(const TableOrderSearch &) = delete;
+    TableOrderSearch &operator=(const TableOrderSearch &) = delete;
+    ~TableOrderSearch() { wait(); }
+    State state() const { return (State)state_.load(std::memory_order_acquire); }
+    bool decided() const { return state() != kIdle; }
+    // false: decided before (by another caller).  background: the search runs in a thread of its own (joined by wait() / the
+    // destructor), else in the caller's.  `d` must outlive the search; `apply` runs in the searching thread, then the state
+    // becomes kDone.
+    bool start(const Dfa2Program &d, std::vector<uint8_t> sample, uint32_t lanes, uint32_t bytes_per_lane, bool background, Apply apply);
+    bool skip();                // kIdle -> kSkipped; false: decided before
+    void wait();                // returns when no search is running any more
+private:
+    std::atomic<int> state_{kIdle};
+    std::mutex mu_;             // guards thread_
+    std::thread thread_;
+};
 
 // The trimmed automaton re-expressed over "positions" (a state split by the character set it is entered on; node 0
 // = the initial state before any input), shrunk by bisimulation quotients and pruning of dominated edges.

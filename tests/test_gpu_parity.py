@@ -803,6 +803,74 @@ def test_block_cooperative_engine_beyond_4096_positions():
     # lines of a only fill the set: both sides of the per-wave skip are in `lines`)
 
 
+def test_bounded_repeat_of_twenty_thousand_copies():
+    """a{1,20000}: 59,999 reference states (under the front end's 65,536), the family the round-3 pipeline did not finish
+    compiling (Parser.cpp:123-141 makes n^2/2 edges by plain copies).  Closed-form answer - a line is accepted
+    iff it is 1..20000 bytes of `a` - through the batch kernel, the one-shot entry, explicit items and the iterator facade."""
+    import time
+    rng = random.Random(91)
+    t0 = time.time()
+    r = rr.RRegex("a{1,20000}")
+    assert time.time() - t0 < 5.0
+    assert r.states_n == 59999 and r.useful_states == 20001 and r.engine_name == "nfa-wave-resident"
+    lines = [b"", b"a", b"aa", b"b", b"a" * 19999, b"a" * 20000, b"a" * 20001, b"a" * 26000, b"a" * 9000 + b"b" + b"a" * 9000,
+             b"a" * 19999 + b"b", b"b" + b"a" * 100, b"a" * 12345 + b"\x80", b"a" * 40000]
+    for _ in range(40):
+        n = rng.choice([rng.randint(1, 300), rng.randint(15000, 25000), rng.randint(19990, 20010)])
+        ln = bytearray(b"a" * n)
+        if rng.random() < 0.3:
+            ln[rng.randrange(n)] = rng.choice(b"bA \x00")
+        lines.append(bytes(ln))
+    want = np.array([1 if 1 <= len(ln) <= 20000 and ln == b"a" * len(ln) else 0 for ln in lines], dtype=np.uint8)
+    assert 10 < want.sum() < len(want) - 10
+    for tail in (b"\n", b""):
+        data = np.frombuffer(b"\n".join(lines) + tail, dtype=np.uint8)
+        dev = torch.from_numpy(data.copy()).cuda()
+        for stripe in (1024, 16384, 0):
+            got = r.match_corpus(rr.Corpus(dev, stripe=stripe)).cpu().numpy()
+            assert got.shape == want.shape and (got == want).all(), (stripe, np.nonzero(got != want)[0][:5])
+        bits, n = r.match_device_bits(dev)
+        assert n == len(lines)
+        got = ((bits.cpu().numpy().view(np.uint32)[np.arange(n) >> 5] >> (np.arange(n) & 31)) & 1).astype(np.uint8)
+        assert (got == want).all(), np.nonzero(got != want)[0][:5]
+    off = np.cumsum([0] + [len(t) for t in lines]).astype(np.int64)
+    blob = torch.from_numpy(np.frombuffer(b"".join(lines), dtype=np.uint8).copy()).cuda()
+    got = r.match_extents(blob, torch.from_numpy(off).cuda()).cpu().numpy()
+    assert (got == want).all(), np.nonzero(got != want)[0][:5]
+    for ln, w in list(zip(lines, want))[:14]:
+        m = r.get_acceptance_iter(ln).advance().value()
+        assert (m is not None) == bool(w), len(ln)
+        if m is not None:
+            assert m.start == 0 and m.end == len(ln)
+    # (ab){1,5000} and (abc|de){1,3000} determinise (10002 / 12002 table states: the table in HBM/L2): same closed forms
+    for p, unit in (("(ab){1,5000}", [b"ab"]), ("(abc|de){1,3000}", [b"abc", b"de"])):
+        r = rr.RRegex(p)
+        top = 5000 if unit == [b"ab"] else 3000
+        ls, ws = [], []
+        for k in [0, 1, 2, top - 1, top, top + 1, top + 50] + [rng.randint(1, top + 200) for _ in range(12)]:
+            ln = b"".join(rng.choice(unit) for _ in range(k))
+            ls.append(ln); ws.append(1 if 1 <= k <= top else 0)
+            if k:
+                ls.append(ln[:-1]); ws.append(int(_units(ln[:-1], unit, top)))
+        data = np.frombuffer(b"\n".join(ls) + b"\n", dtype=np.uint8)
+        got = r.match_corpus(rr.Corpus(torch.from_numpy(data.copy()).cuda())).cpu().numpy()
+        assert list(got) == ws, (p, r.engine_name)
+
+
+def _units(ln, unit, top):
+    """ln is a concatenation of 1..top words of `unit` (words are prefix-free here)."""
+    k = 0
+    while ln:
+        for u in unit:
+            if ln.startswith(u):
+                ln = ln[len(u):]
+                k += 1
+                break
+        else:
+            return False
+    return 1 <= k <= top
+
+
 def test_match_host_pipeline_equals_resident_path():
     """rrx_match_host on an input larger than its 256 MiB chunk: the chunked, double-buffered upload must give
     exactly the accept vector of the device-resident path (and of the oracle on a sampled chunk)."""
@@ -1024,6 +1092,41 @@ def _check_search(pattern, data, want_start, want_end, stripes=(0,)):
                                "want", (int(want_start[bad[0]]), int(want_end[bad[0]])))
 
 
+def _oracle_confirms_search(pattern, lines, first=None, every=None, seed=1, starts_per_match=10):
+    """Search results against the ORACLE's own compile of the pattern, not against a replay of the device's tables.  With
+    `contains` = the oracle's automaton of `.*(p).*` (`.` covers all 128 codes, Parser.cpp:106-109) and `o` that of p:
+      * a line reported without a match: `contains` rejects the whole line (no substring is accepted);
+      * a match [s, e) searched from position b: o accepts line[s:e]; `contains` rejects line[b:e-1] (no match ends earlier - a
+        complete check, one oracle run); no s' in a sample of [b, s) (always b, s-1, s-2) has line[s':e] accepted.
+    `first`: one (s, e) per line; `every`: the list of all matches per line, each searched from the end of the one before."""
+    rng = random.Random(seed)
+    o, contains = OracleRegex(pattern), OracleRegex(".*(" + pattern + ").*")
+
+    def confirm(ln, b, s, e):
+        assert b <= s <= e <= len(ln), (pattern[:30], b, s, e)
+        assert o.accepts(ln[s:e].decode("latin-1")), (pattern[:30], "not a match", s, e)
+        if e - 1 >= b:
+            assert not contains.accepts(ln[b:e - 1].decode("latin-1")), (pattern[:30], "a match ends before", e)
+        for s2 in {b, s - 1, s - 2} | {rng.randrange(b, s) for _ in range(starts_per_match) if s > b}:
+            if b <= s2 < s:
+                assert not o.accepts(ln[s2:e].decode("latin-1")), (pattern[:30], "an earlier start", s2, "for", (s, e))
+
+    for i, ln in enumerate(lines):
+        if first is not None:
+            s, e = first[i]
+            if e < 0:
+                assert not contains.accepts(ln.decode("latin-1")), (pattern[:30], "line", i, "has a match")
+            else:
+                confirm(ln, 0, s, e)
+        if every is not None:
+            b = 0
+            for s, e in every[i]:
+                confirm(ln, b, s, e)
+                b = e if e > s else e + 1                       # (an empty match: the search moves on by one byte)
+            if b <= len(ln):
+                assert not contains.accepts(ln[b:].decode("latin-1")), (pattern[:30], "line", i, "has a further match after", b)
+
+
 def test_search_corpus_short_lines_against_the_oracle():
     """rrx_search_corpus: per line the accepted substring with the smallest end, then the smallest start.  The oracle
     finds it by brute force with the reference's whole-string acceptance (short lines only)."""
@@ -1071,6 +1174,7 @@ def test_search_corpus_long_lines_across_stripes():
             lines += [filler + needle + b" tail", filler, needle + filler, filler[: n // 2] + needle[:3] + filler[n // 2:] + needle]
         data = b"\n".join(lines)
         want = [rep.search(ln) for ln in lines]
+        _oracle_confirms_search(p, lines, first=want)            # the replay's answers are the oracle's
         ws = np.array([w[0] for w in want], dtype=np.int32)
         we = np.array([w[1] for w in want], dtype=np.int32)
         _check_search(p, data, ws, we, stripes=STRIPES)
@@ -1179,6 +1283,7 @@ def test_search_dense_unanchored_matches_against_the_replay():
         lines = data.tobytes()[:-1].split(b"\n")
         first_want = [rep.search(ln) for ln in lines]
         all_want = [rep.search_all(ln) for ln in lines]
+        _oracle_confirms_search(pattern, lines, first=first_want, every=all_want, starts_per_match=3)
         dev = torch.from_numpy(data).cuda()
         for stripe in (1024, 0):
             corpus = rr.Corpus(dev, stripe=stripe)
@@ -1210,6 +1315,7 @@ def test_search_with_tables_beyond_the_chunk_kernels_lds():
     lines = data.tobytes()[:-1].split(b"\n")
     first_want = [rep.search(ln) for ln in lines]
     all_want = [rep.search_all(ln) for ln in lines]
+    _oracle_confirms_search(pattern, lines, first=first_want, every=all_want, starts_per_match=4)
     assert sum(1 for w in first_want if w[1] >= 0) > 100
     corpus = rr.Corpus(torch.from_numpy(data).cuda())
     s, e = r.search_corpus(corpus)

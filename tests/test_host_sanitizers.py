@@ -15,3 +15,12 @@ def test_host_pipeline_is_clean_under_asan_and_ubsan():
     out = subprocess.run(["make", "-C", os.path.join(ROOT, "tools", "sanitize")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "patterns lowered" in out.stdout and "ERROR" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-2000:]
+
+
+@pytest.mark.skipif(shutil.which("g++") is None, reason="no g++")
+def test_order_search_is_clean_under_tsan():
+    """The background table-order search: deciders race (first match / rrx_order_table / skip), pollers
+    read the state the way rrx_table_order does, the owner dies while the search may still run - ThreadSanitizer, CPU build."""
+    out = subprocess.run(["make", "-C", os.path.join(ROOT, "tools", "sanitize"), "tsan"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "no report" in out.stdout and "WARNING: ThreadSanitizer" not in out.stderr, out.stderr[-2000:]
