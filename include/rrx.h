@@ -73,7 +73,10 @@ int         rrx_order_table(rrx_regex *re, const void *sample, uint32_t lanes, u
  * allocate device memory behind the caller's back for the profiled table order above - the table then stays as numbered
  * unless the caller orders it himself with rrx_order_table (which runs in the calling thread).  Set it before the regex'
  * first rrx_match_corpus; a search that is already running is not stopped.  RRX_ERR_ARG for an unknown option.          */
-enum { RRX_OPT_BACKGROUND_ORDER = 1 };
+/* RRX_OPT_UNITS_PER_WORKGROUP (default 0 = off): the stride-2 batch kernel hands its stripes out in units of 64 inside the
+ * workgroup, `value` (16 ... 65536) of them per workgroup of 16 waves, a wave taking its next unit from a counter in LDS.
+ * Same results; measured no faster than one stripe per lane on any config (profiles/r04_unit_handout_ab.txt).           */
+enum { RRX_OPT_BACKGROUND_ORDER = 1, RRX_OPT_UNITS_PER_WORKGROUP = 2 };
 int         rrx_set_option(rrx_regex *re, int option, int64_t value);
 uint32_t    rrx_words_per_set(const rrx_regex *re); /* 32-bit words of the register-resident state set (NFA) */
 int         rrx_accepts_empty(const rrx_regex *re); /* Processor::operator*() on the initial set, NFA.cc:103-107 */

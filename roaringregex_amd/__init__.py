@@ -20,6 +20,7 @@ ENGINE_NFA_SPARSE = 10
 PROGRAM_SEARCH_LINE = 9
 PROGRAM_DFA2_ORDER = 11
 OPT_BACKGROUND_ORDER = 1
+OPT_UNITS_PER_WORKGROUP = 2
 
 # every symbol include/rrx.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = (
@@ -454,6 +455,11 @@ class RRegex:
         """rrx_set_option(RRX_OPT_BACKGROUND_ORDER): False forbids the library's own thread and device allocations for the profiled
         table order (the table stays as numbered unless order_table is called)."""
         _check(_L.rrx_set_option(self._h, OPT_BACKGROUND_ORDER, 1 if enabled else 0))
+
+    def set_units_per_workgroup(self, units):
+        """rrx_set_option(RRX_OPT_UNITS_PER_WORKGROUP): the stride-2 batch kernel hands its stripes out in units of 64 inside
+        the workgroup, `units` of them per workgroup (0: one stripe per lane and launch)."""
+        _check(_L.rrx_set_option(self._h, OPT_UNITS_PER_WORKGROUP, int(units)))
 
     @property
     def table_order(self):

@@ -112,6 +112,7 @@ struct rrx_regex {
     mutable TableOrderSearch t2_order;                   // the order search, in the background or in the caller of rrx_order_table
     mutable Dfa2OrderStats t2_order_stats;               // (under `mu`)
     std::atomic<int> opt_background_order{1};            // RRX_OPT_BACKGROUND_ORDER
+    std::atomic<int> opt_units_per_wg{0};                // RRX_OPT_UNITS_PER_WORKGROUP (0: one stripe per lane and launch)
     mutable std::vector<std::pair<int, void *>> t2_extra_blobs;      // tables uploaded again in the profiled order (device, blob)
     // The stride-2 tables as they go to the device, in the current order: T2 rows of `ncols | 1` entries (odd), R interleaved
     // copies, entry = LDS byte offset of the next row | lines << 16 | verdicts << 24; P = pair -> byte offset of its column.
@@ -702,6 +703,11 @@ int rrx_table_order(const rrx_regex *re, double *conflict_before, double *confli
 int rrx_set_option(rrx_regex *re, int option, int64_t value) {
     if (!re) return fail(RRX_ERR_ARG, "null argument");
     if (option == RRX_OPT_BACKGROUND_ORDER) { re->opt_background_order.store(value ? 1 : 0); return RRX_OK; }
+    if (option == RRX_OPT_UNITS_PER_WORKGROUP) {
+        if (value < 0 || value > 65536) return fail(RRX_ERR_ARG, "units per workgroup: 0 (off) or 16 ... 65536");
+        re->opt_units_per_wg.store(value && value < 16 ? 16 : (int)value);
+        return RRX_OK;
+    }
     return fail(RRX_ERR_ARG, "unknown option");
 }
 uint32_t rrx_byte_classes(const rrx_regex *re) { return re->trimmed.ncls; }
@@ -859,7 +865,9 @@ int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accep
             : re->engine == RRX_ENGINE_NFA
                 ? dev::match_stripes_nfa(t->nfa, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream)
             : (re->has_dfa2 && !c->has_high)
-                ? dev::match_stripes_dfa2(re->dfa2_device(t), c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream)
+                ? (re->opt_units_per_wg.load()
+                       ? dev::match_units_dfa2(re->dfa2_device(t), c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, (uint32_t)re->opt_units_per_wg.load(), stream)
+                       : dev::match_stripes_dfa2(re->dfa2_device(t), c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream))
                 : dev::match_stripes_dfa(t->line, c->has_high, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream);
     if (e) return hip_fail((hipError_t)e, "match_stripes launch");
     return RRX_OK;

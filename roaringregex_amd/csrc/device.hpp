@@ -17,7 +17,7 @@ constexpr int kThreads = RRX_THREADS;       // lanes per workgroup: one LDS copy
 // per CU beat one generation of long-lived waves (the early finishers' slots get refilled while the slowest waves
 // drain), until the per-stripe work (following the straddling line, the final flush) shows: 4 KiB is best at 8 GiB,
 // 2 KiB at 1 GiB.  Automatic choice: about two million lanes, between 2 KiB and 16 KiB; explicit: 1-16 KiB.
-constexpr uint32_t kMinStripe = 1024, kMaxStripe = 16384, kMinAutoStripe = 2048;
+constexpr uint32_t kMinStripe = 512, kMaxStripe = 16384, kMinAutoStripe = 2048;
 constexpr size_t kTargetLanes = (size_t)1 << 21;
 inline uint32_t pick_stripe(size_t nbytes) {
     uint32_t s = kMinAutoStripe;
@@ -32,7 +32,7 @@ inline uint32_t pick_stripe(size_t nbytes) {
 inline uint32_t stripe_for_lines(size_t nbytes, size_t avg_line) {
     uint32_t want = pick_stripe(nbytes);
     while (want < kMaxStripe && avg_line * 16 > want && nbytes / (2 * (size_t)want) >= ((size_t)1 << 17)) want *= 2;
-    while (want > kMinStripe && (avg_line + 1) * 128 < want) want /= 2;
+    while (want > 1024 && (avg_line + 1) * 128 < want) want /= 2;      // (512-byte stripes are for explicit requests)
     return want;
 }
 constexpr int kRound = 128;                      // one whole cache line per lane per round
@@ -138,6 +138,9 @@ constexpr uint32_t kDfa2TableBudget = 30 * 1024;                      // T2 with
 
 int match_stripes_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
                        size_t nstripes, uint32_t *accept_bits, void *stream);
+// the same, stripes handed out in units of 64 inside the workgroup (units_per_wg of them per workgroup of 16 waves)
+int match_units_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
+                     size_t nstripes, uint32_t *accept, uint32_t units_per_wg, void *stream);
 
 // One-pass mode (no line index yet): the stride-2 kernel writes counts[g] ('\n' per stripe, with flags) and every lane's
 // verdict stream into `slabs` (onepass_slab_words() words); after scan_counts, compact_streams moves the streams to their

@@ -104,7 +104,8 @@ struct ResultsT {
     uint32_t outw = 0;
     uint32_t fill;
     uint32_t seen = 0;
-    uint64_t word;                         // STAGED: relative to the first word of the window
+    typename std::conditional<STAGED, uint32_t, uint64_t>::type word;      // STAGED: relative to the first word of the window (a
+                                           //   workgroup's text holds far fewer than 2^37 lines: 32 bits, one register less)
     bool drop_first;
     bool writer = true;                    // wave-cooperative kernels: every lane mirrors the bookkeeping, one writes
     uint32_t *__restrict__ out;            // STAGED: already advanced to the first word of the window
@@ -115,7 +116,7 @@ struct ResultsT {
         word = first_line >> 5; fill = (uint32_t)first_line & 31u; drop_first = drop; out = bitmap;
     }
     __device__ __forceinline__ void begin_staged(uint64_t first_line, uint64_t window_word, bool drop, uint32_t *bitmap, uint32_t *lds) {
-        word = (first_line >> 5) - window_word; fill = (uint32_t)first_line & 31u; drop_first = drop;
+        word = (decltype(word))((first_line >> 5) - window_word); fill = (uint32_t)first_line & 31u; drop_first = drop;
         out = bitmap + window_word; stage = lds;
     }
     __device__ __forceinline__ void emit() {

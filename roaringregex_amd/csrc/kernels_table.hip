@@ -250,31 +250,43 @@ struct Dfa2 {
 // a kernel around this body whose hook writes a timestamp per workgroup and phase (where a launch's fixed cost goes).
 struct NoPhaseHook { __device__ __forceinline__ void operator()(int) const {} __device__ __forceinline__ void round(int) const {} };
 enum { kPhaseEntry = 0, kPhaseTablesLoaded, kPhaseFirstRound, kPhaseMainDone, kPhaseFollowDone, kPhaseWindowOut, kPhases };
-template <bool ONEPASS, class PhaseHook = NoPhaseHook>
-__device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t *__restrict__ bytes, size_t nbytes, uint32_t stripe,
-                                          const uint64_t *__restrict__ stripe_base, uint32_t *__restrict__ accept_bits,
-                                          uint32_t *__restrict__ counts, uint32_t *__restrict__ slabs, PhaseHook phase = PhaseHook()) {
-    phase(kPhaseEntry);
-    // T2 first: its entries hold 16-bit LDS addresses; the result window takes what T2 leaves of its region (16 KiB and
-    // more for tables up to 30 KiB, 4 KiB at least).  The arrays are static, so P's base is a link-time constant.
-    __shared__ __attribute__((aligned(16))) struct {
-        uint8_t t2_and_stage[kDfa2RegionBytes];
-        uint16_t p[kDfa2PBytes / 2];
-    } lds;
-    Dfa2 eng;
-    eng.load(prog, lds.p, lds.t2_and_stage);
-    const uint32_t stage_off = (uint32_t)((Dfa2::lds_bytes(prog) + 15) & ~(size_t)15);
-    uint32_t *const stage = reinterpret_cast<uint32_t *>(lds.t2_and_stage + stage_off);
-    const uint32_t stage_words = (kDfa2RegionBytes - stage_off) / 4;
-    if (!ONEPASS)
-        for (uint32_t i = threadIdx.x; i < stage_words; i += kThreads) stage[i] = 0;
-    __syncthreads();
-    phase(kPhaseTablesLoaded);
-
-    const size_t g0 = (size_t)blockIdx.x * kThreads;
-    uint64_t window_word = 0;
-    if (!ONEPASS) window_word = line_of(stripe_base[g0]) >> 5;       // the workgroup's first stripe exists: uniform load
-    const size_t g = g0 + threadIdx.x;
+// A round's text as ONE burst of eight loads.  ASM: issued from one inline-asm block whose destinations are early-clobber, so the
+// address can never share registers with a destination (the unit kernel's register allocation put the address into the last
+// load's destination: a wait state inside the burst, whose loads then stop merging into one request per 128-byte line).  The
+// compiler does not count loads it cannot see, so the block ends with the wait itself: nothing was ever scheduled between a
+// round's request and its first use anyway (the other waves of the SIMD cover the fetch).
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+template <bool ASM>
+__device__ __forceinline__ void feed_load(uint4 (&buf)[kRound / 16], const uint4 *p) {
+    static_assert(kRound / 16 == 8, "eight slots");
+    if constexpr (!ASM) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) buf[i] = load_text(p + i);
+    } else {
+        u32x4 a, b, c, d, e, f, g, h;
+        asm volatile("global_load_dwordx4 %0, %8, off\n\t"
+                     "global_load_dwordx4 %1, %8, off offset:16\n\t"
+                     "global_load_dwordx4 %2, %8, off offset:32\n\t"
+                     "global_load_dwordx4 %3, %8, off offset:48\n\t"
+                     "global_load_dwordx4 %4, %8, off offset:64\n\t"
+                     "global_load_dwordx4 %5, %8, off offset:80\n\t"
+                     "global_load_dwordx4 %6, %8, off offset:96\n\t"
+                     "global_load_dwordx4 %7, %8, off offset:112\n\t"
+                     "s_waitcnt vmcnt(0)"
+                     : "=&v"(a), "=&v"(b), "=&v"(c), "=&v"(d), "=&v"(e), "=&v"(f), "=&v"(g), "=&v"(h)
+                     : "v"(p)
+                     : "memory");
+        const u32x4 t[8] = {a, b, c, d, e, f, g, h};
+#pragma unroll
+        for (int i = 0; i < 8; i++) buf[i] = make_uint4(t[i].x, t[i].y, t[i].z, t[i].w);
+    }
+}
+// One stripe of one lane: lane-local state only (what the caller keeps across stripes is the engine, the window and `g`).
+template <bool ONEPASS, class PhaseHook, bool FEED_ASM = false>
+__device__ __forceinline__ void dfa2_stripe(const Dfa2 &eng, const size_t g, const uint64_t window_word, uint32_t *const stage, const uint32_t stage_words,
+                                            const uint8_t *__restrict__ bytes, const size_t nbytes, const uint32_t stripe,
+                                            const uint64_t *__restrict__ stripe_base, uint32_t *__restrict__ accept_bits,
+                                            uint32_t *__restrict__ counts, uint32_t *__restrict__ slabs, const uint32_t slab_row, PhaseHook &phase) {
     const size_t start = g * (size_t)stripe;
     if (start < nbytes) {                                            // (no early return: the write-out below is collective)
     const size_t stripe_end = start + stripe;
@@ -282,7 +294,7 @@ __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t 
     bool fresh = true;
     typename std::conditional<ONEPASS, LocalResults, ResultsT<true>>::type res;
     if constexpr (ONEPASS) {
-        res.begin(slabs + g, gridDim.x * kThreads);
+        res.begin(slabs + g, slab_row);
     } else {
         const uint64_t my_base = stripe_base[g];
         fresh = (my_base & kFreshStripe) != 0;
@@ -303,10 +315,7 @@ __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t 
     constexpr int kSlots = kRound / 16;
     const int rounds = (int)((my_end - start) / kRound);
     uint4 buf[kSlots];
-    if (rounds > 0) {
-#pragma unroll
-        for (int i = 0; i < kSlots; i++) buf[i] = load_text(src + i);
-    }
+    if (rounds > 0) feed_load<FEED_ASM>(buf, src);
     // The line that straddles my stripe end is followed into the next stripe's text (below).  Its first 128 bytes are
     // requested while the last round is still being stepped: loaded on demand, 16 bytes at a time, they were a chain of
     // L2 round trips at the end of every wave's life, and the waves of a workgroup - of the whole chip, launched together
@@ -334,13 +343,11 @@ __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t 
         }
         if ((r & 3) == 3) res.flush();
         if (r + 1 < rounds) {
-#pragma unroll
-            for (int i = 0; i < kSlots; i++) buf[i] = load_text(src + (r + 1) * kSlots + i);
+            feed_load<FEED_ASM>(buf, src + (r + 1) * kSlots);
         } else {
             last_word = buf[kSlots - 1].w;
             if (start + (size_t)(rounds + 1) * kRound <= nbytes) {
-#pragma unroll
-                for (int i = 0; i < kSlots; i++) buf[i] = load_text(src + (r + 1) * kSlots + i);
+                feed_load<FEED_ASM>(buf, src + (r + 1) * kSlots);
                 ahead = true;
             }
         }
@@ -380,7 +387,7 @@ __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t 
     if (!closed_by_end_of_data && started && last_byte != '\n') {
         uint32_t lines = 0, verdicts = 0;
         if (ahead && pos == start + (size_t)(rounds + 1) * kRound - kRound) {      // (pos == my_end: the requested bytes are the next ones)
-#pragma unroll
+    #pragma unroll
             for (int i = 0; i < kSlots; i++) {
                 if (!lines) {
                     const uint32_t w[4] = {clean(buf[i].x), clean(buf[i].y), clean(buf[i].z), clean(buf[i].w)};
@@ -409,6 +416,34 @@ __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t 
     if (ONEPASS)
         counts[g] = newlines | ((followed || closed_by_end_of_data) ? kExtraResult : 0u) | (last_byte == '\n' ? kEndsOnNewline : 0u);
     }
+}
+
+template <bool ONEPASS, class PhaseHook = NoPhaseHook>
+__device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t *__restrict__ bytes, size_t nbytes, uint32_t stripe,
+                                          const uint64_t *__restrict__ stripe_base, uint32_t *__restrict__ accept_bits,
+                                          uint32_t *__restrict__ counts, uint32_t *__restrict__ slabs, PhaseHook phase = PhaseHook()) {
+    phase(kPhaseEntry);
+    // T2 first: its entries hold 16-bit LDS addresses; the result window takes what T2 leaves of its region (16 KiB and
+    // more for tables up to 30 KiB, 4 KiB at least).  The arrays are static, so P's base is a link-time constant.
+    __shared__ __attribute__((aligned(16))) struct {
+        uint8_t t2_and_stage[kDfa2RegionBytes];
+        uint16_t p[kDfa2PBytes / 2];
+    } lds;
+    Dfa2 eng;
+    eng.load(prog, lds.p, lds.t2_and_stage);
+    const uint32_t stage_off = (uint32_t)((Dfa2::lds_bytes(prog) + 15) & ~(size_t)15);
+    uint32_t *const stage = reinterpret_cast<uint32_t *>(lds.t2_and_stage + stage_off);
+    const uint32_t stage_words = (kDfa2RegionBytes - stage_off) / 4;
+    if (!ONEPASS)
+        for (uint32_t i = threadIdx.x; i < stage_words; i += kThreads) stage[i] = 0;
+    __syncthreads();
+    phase(kPhaseTablesLoaded);
+
+    const size_t g0 = (size_t)blockIdx.x * kThreads;
+    uint64_t window_word = 0;
+    if (!ONEPASS) window_word = line_of(stripe_base[g0]) >> 5;       // the workgroup's first stripe exists: uniform load
+    dfa2_stripe<ONEPASS>(eng, g0 + threadIdx.x, window_word, stage, stage_words, bytes, nbytes, stripe, stripe_base, accept_bits, counts, slabs,
+                         gridDim.x * kThreads, phase);
     if (!ONEPASS) {
         // ---- write the window out: consecutive lanes, consecutive words (the atomics merge into whole lines in L2;
         // the first and the last word of the window are shared with the neighbouring workgroups)
@@ -419,6 +454,65 @@ __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t 
         }
     }
     phase(kPhaseWindowOut);
+}
+// The same stripes handed out in UNITS inside the workgroup.  A launch of one generation - 1 GiB: 512 workgroups,
+// two per CU - ends in a drain: a SIMD issues from its oldest wave first, its eight waves finish their stripes at 122 ... 228 us and
+// for the last third of the kernel a CU runs on a few waves (profiles/r03_phase_stamps.txt).  Here the workgroup owns
+// `units_per_wg` units of 64 consecutive stripes - several per wave - and a wave that has finished one takes the next from a
+// counter in LDS: the waves the scheduler favours do more units, all sixteen end within one unit of each other.  The unit loop
+// is the outermost scope: nothing lives across iterations but the unit number (scalar); the result window covers the line
+// range of the whole workgroup as before.
+// MEASURED (round 4, profiles/r04_unit_handout_ab.txt, same process A/B): with one unit per wave it runs exactly as the kernel
+// above (0.699 / 0.698 of peak on the 8 GiB headline, 0.605 / 0.596 on a{1,300}); with stripes cut small enough to hand out
+// several units per wave it is SLOWER on every config (email 1 GiB 0.606 -> 0.57-0.58, URL 1 GiB 0.598 -> 0.56-0.58, 8 GiB
+// 0.698 -> 0.66-0.69): what a one-generation launch loses at its end is not an imbalance between waves that a finer hand-out
+// could level.  Kept as an option (RRX_OPT_UNITS_PER_WORKGROUP), off by default.
+template <class PhaseHook = NoPhaseHook>
+__device__ __forceinline__ void dfa2_units_body(const Dfa2Device &prog, const uint8_t *__restrict__ bytes, size_t nbytes, uint32_t stripe,
+                                                const uint64_t *__restrict__ stripe_base, uint32_t *__restrict__ accept_bits, uint32_t units_per_wg,
+                                                PhaseHook phase = PhaseHook()) {
+    phase(kPhaseEntry);
+    __shared__ __attribute__((aligned(16))) struct {
+        uint8_t t2_and_stage[kDfa2RegionBytes];
+        uint16_t p[kDfa2PBytes / 2];
+    } lds;
+    Dfa2 eng;
+    eng.load(prog, lds.p, lds.t2_and_stage);
+    const uint32_t stage_off = (uint32_t)((Dfa2::lds_bytes(prog) + 15) & ~(size_t)15);
+    uint32_t *const stage = reinterpret_cast<uint32_t *>(lds.t2_and_stage + stage_off);
+    const uint32_t stage_words = (kDfa2RegionBytes - stage_off) / 4 - 1;                  // the last word of the region is the unit counter
+    uint32_t &next_unit = stage[stage_words];
+    for (uint32_t i = threadIdx.x; i < stage_words; i += kThreads) stage[i] = 0;
+    if (threadIdx.x == 0) next_unit = kThreads / 64;                 // the first unit of every wave is its own number
+    __syncthreads();
+    phase(kPhaseTablesLoaded);
+    const size_t g_wg = (size_t)blockIdx.x * units_per_wg * 64;      // the workgroup's first stripe (exists: the grid is sized that way)
+    const uint64_t window_word = line_of(stripe_base[g_wg]) >> 5;
+    uint32_t unit = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    while (unit < units_per_wg) {
+        // (the lane number is made anew in every turn, by an instruction the compiler will not hoist: one more register live
+        // across the stripe body and the allocator puts a round's load address into the registers its last load writes - a
+        // wait state inside the burst of eight loads, which then no longer merge into one request per line: -13 %)
+        uint32_t lane;
+        asm volatile("v_and_b32 %0, 63, %1" : "=v"(lane) : "v"(threadIdx.x));
+        dfa2_stripe<false, PhaseHook, true>(eng, g_wg + (size_t)unit * 64 + lane, window_word, stage, stage_words, bytes, nbytes, stripe, stripe_base, accept_bits,
+                           nullptr, nullptr, 0u, phase);
+        uint32_t ticket = 0;
+        if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) ticket = atomicAdd(&next_unit, 1u);
+        unit = __builtin_amdgcn_readfirstlane(ticket);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < stage_words; i += kThreads) {
+        const uint32_t v = stage[i];
+        if (v) atomicOr(&accept_bits[window_word + i], v);
+    }
+    phase(kPhaseWindowOut);
+}
+// (waves_per_eu: left to itself the allocator takes 65 registers here - one workgroup per CU instead of two)
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void match_units2_kernel(
+    Dfa2Device prog, const uint8_t *__restrict__ bytes, size_t nbytes, uint32_t stripe, const uint64_t *__restrict__ stripe_base,
+    uint32_t *__restrict__ accept_bits, uint32_t units_per_wg) {
+    dfa2_units_body(prog, bytes, nbytes, stripe, stripe_base, accept_bits, units_per_wg);
 }
 __global__ __launch_bounds__(kThreads) void match_stripes2_kernel(Dfa2Device prog, const uint8_t *__restrict__ bytes, size_t nbytes,
                                                                    uint32_t stripe, const uint64_t *__restrict__ stripe_base,
@@ -1231,6 +1325,14 @@ int match_stripes_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes,
     if (Dfa2::lds_bytes(p) > kDfa2MaxTable) return (int)hipErrorInvalidValue;
     size_t blocks = (nstripes + kThreads - 1) / kThreads;
     hipLaunchKernelGGL(match_stripes2_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept);
+    return (int)hipGetLastError();
+}
+int match_units_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
+                     size_t nstripes, uint32_t *accept, uint32_t units_per_wg, void *stream) {
+    if (!nstripes) return 0;
+    if (Dfa2::lds_bytes(p) > kDfa2MaxTable || !units_per_wg) return (int)hipErrorInvalidValue;
+    const size_t units = (nstripes + 63) / 64, blocks = (units + units_per_wg - 1) / units_per_wg;
+    hipLaunchKernelGGL(match_units2_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept, units_per_wg);
     return (int)hipGetLastError();
 }
 // byte-stride table engines in one-pass mode (bytes >= 0x80 are always clamped: nobody has looked at the corpus yet)

@@ -399,6 +399,43 @@ def test_profiled_table_order_changes_no_result():
     assert small.table_order is None
 
 
+def test_units_handed_out_inside_the_workgroup_change_no_result():
+    """RRX_OPT_UNITS_PER_WORKGROUP: the stride-2 kernel with its stripes handed out in units of 64 from a counter in LDS (a wave
+    takes several) - against the oracle on ragged text at 512-byte to 4 KiB stripes, workgroups that end inside the corpus, units
+    beyond the last stripe; and bit for bit against the one-stripe-per-lane kernel on 96 MiB of the URL corpus."""
+    import synth
+    rng = np.random.default_rng(61)
+    p = "(a|b)*abb(a|b)*"
+    o = OracleRegex(p)
+    alphabet = np.frombuffer(b"ab\n", dtype=np.uint8)
+    for n, probs in ((3_000_017, [0.46, 0.46, 0.08]), (1_200_000, [0.4995, 0.4995, 0.001]), (70_001, [0.3, 0.3, 0.4])):
+        data = alphabet[rng.choice(3, size=n, p=probs)].copy()
+        want = o.match_lines(data)
+        dev = torch.from_numpy(data).cuda()
+        for stripe in (512, 1024, 4096):
+            corpus = rr.Corpus(dev, stripe=stripe)
+            for units in (16, 17, 40, 4096):
+                r = rr.RRegex(p)
+                assert r.engine_name == "dfa-stride2-table"
+                r.set_units_per_workgroup(units)
+                got = r.match_corpus(corpus).cpu().numpy()
+                assert got.shape == want.shape and (got == want).all(), (n, stripe, units, np.nonzero(got != want)[0][:4])
+    data = synth.corpus("url", 2, 96 << 20)
+    dev = torch.from_numpy(data).cuda()
+    plain = rr.RRegex(U2)
+    plain.set_background_order(False)
+    for stripe in (512, 2048):
+        corpus = rr.Corpus(dev, stripe=stripe)
+        ref = plain.match_corpus_bits(corpus).clone()
+        for units in (32, 64):
+            r = rr.RRegex(U2)
+            r.set_background_order(False)
+            r.set_units_per_workgroup(units)
+            assert torch.equal(r.match_corpus_bits(corpus), ref), (stripe, units)
+    with pytest.raises(rr.RRegexError):
+        plain.set_units_per_workgroup(1 << 20)
+
+
 def test_table_order_from_a_caller_sample_after_the_tables_are_up():
     """rrx_order_table on a regex whose tables are already on the device (it matched a small corpus first): the stride-2 arrays
     are uploaded again in the new order and swapped in; results before and after are the oracle's."""

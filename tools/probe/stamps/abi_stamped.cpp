@@ -3,6 +3,8 @@
 namespace rrx { namespace dev {
 int match_stripes_dfa2_stamped(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
                                size_t nstripes, uint32_t *accept, uint64_t *stamps, uint64_t *rounds, void *stream);
+int match_units_dfa2_stamped(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
+                             size_t nstripes, uint32_t *accept, uint32_t units_per_wg, uint64_t *stamps, uint64_t *rounds, void *stream);
 int stamp_columns();
 } }
 extern "C" int rrx_probe_stamp_columns(void) { return rrx::dev::stamp_columns(); }
@@ -13,7 +15,9 @@ extern "C" int rrx_probe_match_stamped(const rrx_regex *re, const rrx_corpus *c,
     if (rc) return rc;
     if (!re->has_dfa2 || c->has_high) return fail(RRX_ERR_UNSUPPORTED, "stamps: the stride-2 engine only");
     HIP_TRY(hipMemsetAsync(d_accept_bits, 0, rrx_corpus_bitmap_words(c) * sizeof(uint32_t), (hipStream_t)stream));
-    int e = dev::match_stripes_dfa2_stamped(t->dfa2, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, d_stamps, d_rounds, stream);
+    const uint32_t upw = (uint32_t)re->opt_units_per_wg.load();
+    int e = upw ? dev::match_units_dfa2_stamped(t->dfa2, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, upw, d_stamps, d_rounds, stream)
+                : dev::match_stripes_dfa2_stamped(t->dfa2, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, d_stamps, d_rounds, stream);
     if (e) return hip_fail((hipError_t)e, "stamped launch");
     return RRX_OK;
 }

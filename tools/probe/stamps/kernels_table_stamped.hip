@@ -31,7 +31,29 @@ __global__ __launch_bounds__(kThreads) void match_stripes2_stamped_kernel(Dfa2De
     }
     dfa2_body<false, StampHook>(prog, bytes, nbytes, stripe, stripe_base, accept_bits, nullptr, nullptr, StampHook{row, rounds + (size_t)blockIdx.x * (kThreads / 64) * kMaxRounds});
 }
+__global__ __launch_bounds__(kThreads) void match_units2_stamped_kernel(Dfa2Device prog, const uint8_t *__restrict__ bytes, size_t nbytes,
+                                                                         uint32_t stripe, const uint64_t *__restrict__ stripe_base,
+                                                                         uint32_t *__restrict__ accept_bits, uint32_t units_per_wg, uint64_t *__restrict__ stamps,
+                                                                         uint64_t *__restrict__ rounds) {
+    uint64_t *row = stamps + (size_t)blockIdx.x * (kThreads / 64) * (kPhases + 2);      // a row per wave (the last unit of a wave overwrites)
+    if ((threadIdx.x & 63) == 0) {
+        uint64_t *mine = row + (threadIdx.x >> 6) * (kPhases + 2);
+        uint32_t xcc, hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        mine[kPhases] = xcc & 0xf;
+        mine[kPhases + 1] = hw;
+    }
+    dfa2_units_body<StampHook>(prog, bytes, nbytes, stripe, stripe_base, accept_bits, units_per_wg, StampHook{row, rounds + (size_t)blockIdx.x * (kThreads / 64) * kMaxRounds});
+}
 }  // namespace
+int match_units_dfa2_stamped(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
+                             size_t nstripes, uint32_t *accept, uint32_t units_per_wg, uint64_t *stamps, uint64_t *rounds, void *stream) {
+    if (!nstripes) return 0;
+    const size_t units = (nstripes + 63) / 64, blocks = (units + units_per_wg - 1) / units_per_wg;
+    hipLaunchKernelGGL(match_units2_stamped_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept, units_per_wg, stamps, rounds);
+    return (int)hipGetLastError();
+}
 int match_stripes_dfa2_stamped(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
                                size_t nstripes, uint32_t *accept, uint64_t *stamps, uint64_t *rounds, void *stream) {
     if (!nstripes) return 0;

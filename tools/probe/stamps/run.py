@@ -9,12 +9,15 @@ import numpy as np, torch
 import roaringregex_amd as rr, synth, bench
 workload, nbytes = sys.argv[1], int(sys.argv[2])
 stripe = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+units = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 kind, pkey, _, _ = bench.WORKLOADS[workload]
 pattern = bench.patterns()[pkey]
 host = np.empty(nbytes, dtype=np.uint8); synth.fill(kind, 2, host, threads=8)
 dev = torch.from_numpy(host).cuda()
 corpus = rr.Corpus(dev, stripe=stripe)
 r = rr.RRegex(pattern)
+r.set_background_order(False)
+if units: r.set_units_per_workgroup(units)
 L = rr._L
 L.rrx_probe_stamp_columns.restype = C.c_int
 cols = L.rrx_probe_stamp_columns()
@@ -40,6 +43,7 @@ names = ["entry", "tables loaded", "first round done", "main loop done", "follow
 t0 = S[:, :, 0].min()
 T = (S[:, :, :6] - t0) / 100.0            # 100 MHz -> us ; [wg][wave][phase]
 np.save(os.path.join(ROOT, "gpurun_out", "stamps_%s_%d.npy" % (workload, nbytes >> 20)), S)
+print("== units/wg %d" % units)
 print("== workload %s  %d MiB  stripe %d  workgroups %d  event time %.1f us  stamped span %.1f us" % (workload, nbytes >> 20, corpus.stripe, len(S), ms * 1e3, T[:, :, 5].max()))
 def q(a): return "min %7.1f  med %7.1f  p90 %7.1f  max %7.1f" % (a.min(), np.median(a), np.percentile(a, 90), a.max())
 W = T.reshape(-1, 6)
