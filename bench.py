@@ -157,6 +157,9 @@ def main():
     ap.add_argument("--stripe", type=int, default=0, help="bytes per GPU lane (0 = chosen from the corpus size)")
     ap.add_argument("--pcie", action="store_true", help="also time the host-buffer entry (upload + index + match + download)")
     ap.add_argument("--search", action="store_true", help="also time rrx_search_corpus (match offsets per line) on the same corpus")
+    ap.add_argument("--shard-one-corpus", action="store_true",
+                    help="ONE corpus of gpus x bytes, cut after '\\n' into one byte range per rank (roaringregex_amd.shard) - SURVEY 8(e) to the "
+                         "letter; default: every rank generates a corpus of its own (the same work per GPU)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
@@ -224,8 +227,29 @@ def main():
     # ---- synthetic shard of this rank (seed differs per rank), generated on the host cores, then resident in HBM
     t0 = time.perf_counter()
     threads = max(1, min(len(os.sched_getaffinity(0)), 64) // max(1, world))
-    host = np.empty(nbytes, dtype=np.uint8)
-    synth.fill(kind, 2 + 1000 * rank, host, threads=threads)
+    sharding = "by lines, no collective"
+    if args.shard_one_corpus:
+        # one corpus of world x nbytes bytes (seed 2), never materialised whole: every rank finds the cuts from the bytes around the
+        # world - 1 targets and generates its own range only (the generator's 1 MiB chunks are independent of each other)
+        from roaringregex_amd.shard import line_aligned_cuts
+        MiB = 1 << 20
+        total = world * nbytes
+
+        def fetch(lo, hi):
+            first = lo // MiB * MiB
+            buf = np.empty((hi - first + MiB - 1) // MiB * MiB, dtype=np.uint8)
+            synth.fill_window(kind, 2, first, buf, threads=1)
+            return buf[lo - first:hi - first]
+
+        lo, hi = line_aligned_cuts(fetch, total, world)[rank]
+        assert lo % MiB == 0, "the generator's chunks end with a newline: a cut at a multiple of a chunk stays there"
+        host = np.empty(hi - lo, dtype=np.uint8)
+        synth.fill_window(kind, 2, lo, host, threads=threads)
+        nbytes = hi - lo
+        sharding = "one corpus of %d bytes cut after '\\n' (shard.line_aligned_cuts), rank r scans range r; no collective" % total
+    else:
+        host = np.empty(nbytes, dtype=np.uint8)
+        synth.fill(kind, 2 + 1000 * rank, host, threads=threads)
     gen_s = time.perf_counter() - t0
     dev = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
     piece = 1 << 30
@@ -330,7 +354,7 @@ def main():
                                    % (config_name, regex.states_n, "BitSet<%d>" % regex.set_class if regex.set_class else "Roaring", nbytes / 2**30),
                        "pattern_states": regex.states_n, "useful_states": regex.useful_states, "engine": regex.engine_name,
                        "table_order_profiled_conflicts_before_after": regex.table_order, "table_order_wait_ms": round(order_wait_ms, 1),
-                       "bytes_per_gpu": nbytes, "stripe_bytes": corpus.stripe, "lines_per_gpu": nlines, "accepted_rank0": accepted, "sharding": "by lines, no collective"},
+                       "bytes_per_gpu": nbytes, "stripe_bytes": corpus.stripe, "lines_per_gpu": nlines, "accepted_rank0": accepted, "sharding": sharding},
             "per_gpu_GBs": round(nbytes * args.steps / elapsed / 1e9, 2),
             "per_rank_GBs": per_rank,
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

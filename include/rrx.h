@@ -144,10 +144,13 @@ int rrx_search_all(const rrx_regex *re, const rrx_corpus *corpus, uint64_t *d_fi
                    size_t cap, size_t *total, void *stream);
 
 /* explicit extents: item i = d_bytes[d_off[i] .. d_off[i+1] - trim); '\n' is an ordinary character here.  Asynchronous on
- * `stream` (nothing is read back).  Large batches on a table engine (>= 65536 items) build an item index in a scratch buffer
- * the regex handle keeps until rrx_free (1 bit per byte of what is left of the allocation behind d_bytes, + 8 bytes per
- * stripe; an allocation with more than 8 GiB left behind d_bytes is not trusted as a bound: the batch extent is read back,
- * one synchronisation); calls with one regex on different streams are ordered on the device by an event, not on the host. */
+ * `stream`.  Large batches on a table engine (>= 65536 items) build an item index in a scratch buffer the regex handle keeps
+ * until rrx_free (1 bit per byte + 8 bytes per stripe of the batch's extent).  The host does not know the extent; it takes
+ * what is left of the allocation behind d_bytes (hipMemGetAddressRange) as its bound and nothing is read back - as long as
+ * that bound is plausible for the batch, at most max(128 bytes per item, 16 MiB).  A batch inside a far larger allocation (a
+ * memory pool, a caching allocator's block) and memory whose range the runtime does not report (pool, virtual or managed
+ * memory) cost one synchronisation on `stream`: d_off[0] and d_off[nitems] are read back.  Calls with one regex on
+ * different streams are ordered on the device by an event, not on the host.                                               */
 int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, const uint64_t *d_off, size_t nitems,
                       uint32_t trim, uint8_t *d_accept, void *stream);
 

@@ -1157,14 +1157,22 @@ int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, cons
             bound = (size_t)(static_cast<const uint8_t *>(abase) + asize - b);
         else (void)hipGetLastError();
     }
-    // (an allocation far larger than any batch - a memory pool - would size the index for all of it: beyond 8 GiB left behind
-    // d_bytes the batch's real extent is read back instead, one synchronisation, as round 2 did for every batch)
-    if (items && bound > ((size_t)8 << 30)) {
-        uint64_t first = 0, last = 0;
-        HIP_TRY(hipMemcpyAsync(&first, d_off, sizeof first, hipMemcpyDeviceToHost, (hipStream_t)stream));
-        HIP_TRY(hipMemcpyAsync(&last, d_off + nitems, sizeof last, hipMemcpyDeviceToHost, (hipStream_t)stream));
-        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-        bound = last > first ? (size_t)last : 0;                  // (the kernels still take the extent from the offsets)
+    // The tail of the allocation is only a BOUND: a batch carved out of a memory pool (a caching allocator's block, a slice of a
+    // column store) would size the index, the stripe and the grids for all of the pool behind it - a 24 MiB batch 6 GiB into a
+    // 10 GiB pool: 512 MiB of scratch and two workgroups' worth of stripes.  So the bound is trusted only while it is plausible
+    // for the batch: at most 128 bytes per item (string columns; 16 MiB at least).  Beyond that - and for memory whose range
+    // the runtime does not report (pools, managed and virtual memory: bound 0) - the batch's real extent is read back, one
+    // synchronisation on `stream`, as round 2 did for every batch.  (The kernels take the extent from the offsets either way.)
+    if (items) {
+        const size_t plausible = std::max<size_t>(nitems * 128, (size_t)16 << 20);
+        if (!bound || bound > plausible) {
+            uint64_t first = 0, last = 0;
+            HIP_TRY(hipMemcpyAsync(&first, d_off, sizeof first, hipMemcpyDeviceToHost, (hipStream_t)stream));
+            HIP_TRY(hipMemcpyAsync(&last, d_off + nitems, sizeof last, hipMemcpyDeviceToHost, (hipStream_t)stream));
+            HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+            const size_t extent = last > first ? (size_t)last : 0;
+            bound = bound ? std::min(bound, extent) : extent;
+        }
     }
     if (items && bound >= kItemsStripesMinBytes) {
         hipStream_t st = (hipStream_t)stream;

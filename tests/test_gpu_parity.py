@@ -908,6 +908,66 @@ def _units(ln, unit, top):
     return 1 <= k <= top
 
 
+def _sharded_rank(rank, world, port, q):
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "oracle"), os.path.join(root, "tools"), os.path.join(root, "tests")):
+        sys.path.insert(0, p)
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import roaringregex_amd as rr
+    import synth
+    from patterns import U2
+    from roaringregex_amd.shard import match_sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)                                  # a one-GPU box: both ranks share the card, gloo carries the results
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        data = synth.corpus("url", 9, 24 << 20, threads=2)[:-11]       # an unterminated last line on purpose
+        r = rr.RRegex(U2)
+        whole = match_sharded(lambda shard: r.match_corpus(rr.Corpus(torch.from_numpy(np.ascontiguousarray(shard)).cuda())), data, rank, world)
+        q.put((rank, synth.fnv1a(whole), int(whole.size), int(whole.sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_one_corpus_sharded_with_the_hip_matcher():
+    """SURVEY 8(e) to the letter: ONE corpus cut into line-aligned byte ranges (roaringregex_amd.shard), every rank scans its range
+    with RRegex.match_corpus, the accept vectors concatenated in rank order - at world 1 in this process, at world 2 in two
+    processes over gloo (both on GPU 0): equal to the unsharded HIP result and, on a sample, to the oracle."""
+    import socket
+    import synth
+    import torch.multiprocessing as mp
+    from roaringregex_amd.shard import match_sharded
+    data = synth.corpus("url", 9, 24 << 20, threads=2)[:-11]
+    r = rr.RRegex(U2)
+    unsharded = r.match_corpus(rr.Corpus(torch.from_numpy(data.copy()).cuda())).cpu().numpy()
+    one = match_sharded(lambda shard: r.match_corpus(rr.Corpus(torch.from_numpy(np.ascontiguousarray(shard)).cuda())), data, 0, 1)
+    assert one.shape == unsharded.shape and (one == unsharded).all()
+    head = data[:1 << 20]
+    cut = int(np.flatnonzero(head == 10)[-1]) + 1
+    want = OracleRegex(U2).match_lines(head[:cut])
+    assert (unsharded[:len(want)] == want).all() and 0 < want.sum() < len(want)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_sharded_rank, args=(k, 2, port, q)) for k in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, h, n, acc in res:
+        assert (h, n, acc) == (synth.fnv1a(unsharded), unsharded.size, int(unsharded.sum())), rank
+
+
 def test_match_host_pipeline_equals_resident_path():
     """rrx_match_host on an input larger than its 256 MiB chunk: the chunked, double-buffered upload must give
     exactly the accept vector of the device-resident path (and of the oracle on a sampled chunk)."""
@@ -1049,8 +1109,8 @@ def test_explicit_items_stripe_wise():
 
 
 def test_explicit_items_inside_a_far_larger_allocation():
-    """rrx_match_extents sizes its index for what is left of the allocation behind d_bytes; with more than 8 GiB left (a batch at
-    the front of a memory pool) it reads the batch's real extent back instead (one synchronisation).  Same answers as on a buffer
+    """rrx_match_extents takes what is left of the allocation behind d_bytes as the bound of its index only while that is plausible for
+    the batch (128 bytes per item); a batch inside a memory pool has its real extent read back instead (one synchronisation).  Same answers as on a buffer
     of the batch's own size, from the front and from the middle of a 10 GiB allocation."""
     import synth
     n = 24 << 20
@@ -1062,11 +1122,27 @@ def test_explicit_items_inside_a_far_larger_allocation():
     r = rr.RRegex(U2)
     want = r.match_extents(small, off, trim=1)
     assert int(want.sum()) > 1000
+    def rate(data):
+        out = torch.empty(off.numel() - 1, dtype=torch.uint8, device="cuda")
+        for _ in range(3):
+            r.match_extents(data, off, trim=1, out=out)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(5):
+            r.match_extents(data, off, trim=1, out=out)
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / 5
+
+    alone_ms = rate(small)
     pool = torch.empty(10 << 30, dtype=torch.uint8, device="cuda")
-    for at in (0, 6 << 30):                                                  # (6 GiB in: 4 GiB left - the asynchronous path, bound >> extent)
+    for at in (0, 6 << 30):                                                  # (6 GiB in: 4 GiB left behind the batch)
         pool[at:at + last] = small
         got = r.match_extents(pool[at:at + last], off, trim=1)
         assert torch.equal(got, want), at
+        # sized from the pool's tail the batch ran on two workgroups' worth of stripes and took 512 MiB of scratch;
+        # sized from its own extent it runs as it does alone (one synchronisation more)
+        assert rate(pool[at:at + last]) < 2.0 * alone_ms + 0.1, (at, alone_ms)
     del pool
     torch.cuda.empty_cache()
 

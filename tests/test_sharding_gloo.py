@@ -7,7 +7,7 @@ import socket
 import numpy as np
 import pytest
 
-from roaringregex_amd.shard import line_aligned_ranges, lines_in
+from roaringregex_amd.shard import line_aligned_cuts, line_aligned_ranges, lines_in
 
 torch = pytest.importorskip("torch")
 
@@ -24,6 +24,8 @@ def test_ranges_are_line_aligned_and_cover():
             for s, _ in r:
                 assert s == 0 or s == n or a[s - 1] == 10
             assert sum(lines_in(a[s:e]) for s, e in r) == lines_in(a)
+            # the same cuts through a byte fetcher (a corpus that is not in one array: bench.py --shard-one-corpus)
+            assert line_aligned_cuts(lambda lo, hi: a[lo:hi], n, world, window=97) == r
     # no newline at all: everything stays on rank 0's... first shard that reaches the end
     a = np.frombuffer(b"x" * 1000, dtype=np.uint8)
     r = line_aligned_ranges(a, 4)

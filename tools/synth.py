@@ -25,6 +25,8 @@ def _lib():
         L = C.CDLL(so)
         L.synth_fill.restype = C.c_int
         L.synth_fill.argtypes = [C.c_int, C.c_uint64, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
+        L.synth_fill_window.restype = C.c_int
+        L.synth_fill_window.argtypes = [C.c_int, C.c_uint64, C.c_uint64, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
         L.synth_fnv1a.restype = C.c_uint64
         L.synth_fnv1a.argtypes = [C.c_void_p, C.c_size_t]
         _LIB = L
@@ -38,6 +40,19 @@ def fill(kind, seed, out, chunk=0, threads=None):
     rc = _lib().synth_fill(KIND[kind] if isinstance(kind, str) else kind, seed, C.c_void_p(out.ctypes.data), out.size, chunk, threads)
     if rc:
         raise RuntimeError("synth_fill failed: %d" % rc)
+    return out
+
+
+def fill_window(kind, seed, first_byte, out, chunk=0, threads=None):
+    """out = bytes [first_byte, first_byte + out.size) of the corpus (kind, seed); first_byte: a multiple of the chunk (1 MiB).
+    A window of a corpus of any size without generating the rest (chunks are independent and end with '\\n')."""
+    step = chunk or (1 << 20)
+    assert first_byte % step == 0
+    if threads is None:
+        threads = min(os.cpu_count() or 1, 64)
+    rc = _lib().synth_fill_window(KIND[kind] if isinstance(kind, str) else kind, seed, first_byte // step, C.c_void_p(out.ctypes.data), out.size, chunk, threads)
+    if rc:
+        raise RuntimeError("synth_fill_window failed: %d" % rc)
     return out
 
 
