@@ -73,11 +73,27 @@ int         rrx_order_table(rrx_regex *re, const void *sample, uint32_t lanes, u
  * allocate device memory behind the caller's back for the profiled table order above - the table then stays as numbered
  * unless the caller orders it himself with rrx_order_table (which runs in the calling thread).  Set it before the regex'
  * first rrx_match_corpus; a search that is already running is not stopped.  RRX_ERR_ARG for an unknown option.          */
+/* RRX_OPT_SAMPLED_TABLE (default 1): 0 keeps an automaton whose subset construction explodes on the NFA lane engine for every
+ * launch (see rrx_learn_table).                                                                                          */
 /* RRX_OPT_UNITS_PER_WORKGROUP (default 0 = off): the stride-2 batch kernel hands its stripes out in units of 64 inside the
  * workgroup, `value` (16 ... 65536) of them per workgroup of 16 waves, a wave taking its next unit from a counter in LDS.
  * Same results; measured no faster than one stripe per lane on any config (profiles/r04_unit_handout_ab.txt).           */
-enum { RRX_OPT_BACKGROUND_ORDER = 1, RRX_OPT_UNITS_PER_WORKGROUP = 2 };
+enum { RRX_OPT_BACKGROUND_ORDER = 1, RRX_OPT_UNITS_PER_WORKGROUP = 2, RRX_OPT_SAMPLED_TABLE = 3 };
 int         rrx_set_option(rrx_regex *re, int option, int64_t value);
+/* The SAMPLED TABLE (an automaton that does not determinise - AUTO leaves it on the NFA lane engine - over text whose live sets
+ * are few, README.md:18-21): the state sets a text sample reaches are interned into a table, every transition the sample and a
+ * bounded closure leave open leads to an ESCAPE state.  rrx_match_corpus then runs the stride-2 table kernel (two result bits
+ * per line: accepted, escaped) and lets the NFA engine decide the escaped lines: the result is exact for ANY text, text that
+ * resembles the sample runs at table speed.  Built once per regex: by the first rrx_match_corpus against a corpus of 64 MiB or
+ * more, from the corpus' own sample, in a background thread (RRX_OPT_BACKGROUND_ORDER 0: in the caller's) - or here, from `text`
+ * (host memory, whole lines; the first line fragment is skipped), in the caller's thread.  RRX_ERR_UNSUPPORTED: the regex is
+ * not on the NFA lane engine by AUTO's choice, or no table fits.  rrx_sampled_table: 1 = in use, 2 = being built, 0 = none;
+ * *table_states, *open_transitions (entries that lead to ESCAPE) describe it.  Host only.                                  */
+int         rrx_learn_table(rrx_regex *re, const void *text, size_t nbytes);
+int         rrx_sampled_table(const rrx_regex *re, uint32_t *table_states, uint32_t *open_transitions);
+/* *lines = the number of lines the NFA engine had to decide in the regex' LAST sampled-table launch on `device` (synchronous:
+ * waits for the device).  A table whose escapes stay above a few per cent of the lines was learnt from the wrong text.      */
+int         rrx_sampled_escapes(const rrx_regex *re, int device, uint64_t *lines);
 uint32_t    rrx_words_per_set(const rrx_regex *re); /* 32-bit words of the register-resident state set (NFA) */
 int         rrx_accepts_empty(const rrx_regex *re); /* Processor::operator*() on the initial set, NFA.cc:103-107 */
 /* Serialised device program as 32-bit words (layout: DESIGN.md "Device programs"); returns the word count
@@ -91,6 +107,9 @@ int         rrx_accepts_empty(const rrx_regex *re); /* Processor::operator*() on
 #define RRX_PROGRAM_SEARCH_LINE 9  /* the forward table as the stripe-wise search kernel runs it: [nrows, ncols, start row,
                                       SKIP row, column of byte[256], entry[nrows][ncols]], entry = next row | '\n' << 16 |
                                       hit << 17 | match-starts-at-the-line-start << 18 (0 words: form not available)   */
+#define RRX_PROGRAM_SAMPLED_DFA 12  /* the sampled table (rrx_learn_table): the DFA layout, then escaped[nstates] (1: the ESCAPE state) */
+#define RRX_PROGRAM_SAMPLED_DFA2 13 /* its stride-2 form as the kernel runs it: the DFA2 layout, byte 2 of an entry = RESULT BITS shifted
+                                       in (two per line end: accepted, escaped), byte 3 = those bits                          */
 size_t rrx_program_words(const rrx_regex *re, int kind, uint32_t *out, size_t cap);
 
 /* ---- batch of strings: the replacement for calling get_acceptance_iter(line)++ per string ------------ *

@@ -19,14 +19,17 @@ ENGINE_NFA_BLOCK = 8
 ENGINE_NFA_SPARSE = 10
 PROGRAM_SEARCH_LINE = 9
 PROGRAM_DFA2_ORDER = 11
+PROGRAM_SAMPLED_DFA = 12
+PROGRAM_SAMPLED_DFA2 = 13
 OPT_BACKGROUND_ORDER = 1
 OPT_UNITS_PER_WORKGROUP = 2
+OPT_SAMPLED_TABLE = 3
 
 # every symbol include/rrx.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = (
     "rrx_compile", "rrx_compile_ex", "rrx_free", "rrx_last_error",
     "rrx_num_states", "rrx_set_class", "rrx_ref_initial", "rrx_ref_is_final", "rrx_ref_row",
-    "rrx_engine", "rrx_engine_name", "rrx_useful_states", "rrx_byte_classes", "rrx_table_order", "rrx_order_table", "rrx_set_option", "rrx_words_per_set", "rrx_accepts_empty",
+    "rrx_engine", "rrx_engine_name", "rrx_useful_states", "rrx_byte_classes", "rrx_table_order", "rrx_order_table", "rrx_set_option", "rrx_learn_table", "rrx_sampled_table", "rrx_sampled_escapes", "rrx_words_per_set", "rrx_accepts_empty",
     "rrx_program_words",
     "rrx_corpus_create", "rrx_corpus_create_ex", "rrx_corpus_stripe_bytes", "rrx_corpus_num_lines", "rrx_corpus_num_bytes", "rrx_corpus_free", "rrx_corpus_bitmap_words",
     "rrx_match_corpus", "rrx_match_device", "rrx_search_corpus", "rrx_search_all_count", "rrx_search_all_fill", "rrx_search_all", "rrx_bitmap_to_bytes",
@@ -69,6 +72,9 @@ def _load():
         "rrx_byte_classes": (u32, [vp]),
         "rrx_table_order": (i32, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "rrx_set_option": (i32, [vp, i32, C.c_int64]),
+        "rrx_learn_table": (i32, [vp, vp, C.c_size_t]),
+        "rrx_sampled_table": (i32, [vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+        "rrx_sampled_escapes": (i32, [vp, i32, C.POINTER(C.c_uint64)]),
         "rrx_order_table": (i32, [vp, vp, u32, u32]),
         "rrx_words_per_set": (u32, [vp]),
         "rrx_accepts_empty": (i32, [vp]),
@@ -455,6 +461,33 @@ class RRegex:
         """rrx_set_option(RRX_OPT_BACKGROUND_ORDER): False forbids the library's own thread and device allocations for the profiled
         table order (the table stays as numbered unless order_table is called)."""
         _check(_L.rrx_set_option(self._h, OPT_BACKGROUND_ORDER, 1 if enabled else 0))
+
+    def learn_table(self, text):
+        """rrx_learn_table: build the sampled table (an automaton AUTO leaves on the NFA lane engine) from a text sample - bytes or a
+        numpy uint8 array of whole lines.  Returns (table states, open transitions)."""
+        import numpy as np
+        a = np.frombuffer(text, dtype=np.uint8) if isinstance(text, (bytes, bytearray)) else np.ascontiguousarray(text, dtype=np.uint8)
+        _check(_L.rrx_learn_table(self._h, C.c_void_p(a.ctypes.data), a.size))
+        return self.sampled_table
+
+    def set_sampled_table(self, enabled):
+        _check(_L.rrx_set_option(self._h, OPT_SAMPLED_TABLE, 1 if enabled else 0))
+
+    @property
+    def sampled_table(self):
+        """None, or (table states, open transitions) of the sampled table in use."""
+        n, o = C.c_uint32(0), C.c_uint32(0)
+        return (n.value, o.value) if _L.rrx_sampled_table(self._h, C.byref(n), C.byref(o)) == 1 else None
+
+    def sampled_escapes(self):
+        """Lines the NFA engine had to decide in the last sampled-table launch on this regex' device (waits for the device)."""
+        n = C.c_uint64(0)
+        _check(_L.rrx_sampled_escapes(self._h, self.device, C.byref(n)))
+        return n.value
+
+    @property
+    def sampled_table_pending(self):
+        return _L.rrx_sampled_table(self._h, None, None) == 2
 
     def set_units_per_workgroup(self, units):
         """rrx_set_option(RRX_OPT_UNITS_PER_WORKGROUP): the stride-2 batch kernel hands its stripes out in units of 64 inside

@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -113,19 +114,74 @@ struct rrx_regex {
     mutable Dfa2OrderStats t2_order_stats;               // (under `mu`)
     std::atomic<int> opt_background_order{1};            // RRX_OPT_BACKGROUND_ORDER
     std::atomic<int> opt_units_per_wg{0};                // RRX_OPT_UNITS_PER_WORKGROUP (0: one stripe per lane and launch)
+    std::atomic<int> opt_sampled_table{1};               // RRX_OPT_SAMPLED_TABLE
+    // ---- the sampled table: AUTO ended on the NFA lane engine because the subset construction explodes; the sets a
+    // text sample reaches are interned into a table with an ESCAPE state, the batch entry runs the stride-2 kernel on it (two result
+    // bits per line) and lets the NFA engine decide the lines that escaped.  Built once: by the first rrx_match_corpus against a
+    // corpus that carries a sample (in the background), or by rrx_learn_table (in the caller's thread).
+    int requested_engine = 0;
+    mutable OnceTask sampled_build;
+    mutable std::atomic<bool> sampled_ready{false};      // (set under `mu` after the programs below are complete)
+    mutable DfaProgram sampled_dfa;
+    mutable Dfa2Program sampled_dfa2;
+    mutable SampledTableStats sampled_stats;
+    struct SampledOnDevice { void *blob = nullptr; dev::Dfa2Device d; };
+    mutable std::map<int, const void *> sampled_counter;   // device -> where the last launch counted its escaped lines (under onepass_mu)
+    mutable std::map<int, SampledOnDevice> sampled_on_device;
+    bool sampled_eligible() const { return requested_engine == RRX_ENGINE_AUTO && engine == RRX_ENGINE_NFA && !has_dfa && has_nfa; }
+    // pieces x piece_bytes of text -> the table; false: nothing usable came out (the engine stays as it is)
+    bool build_sampled(const uint8_t *text, uint32_t pieces, uint32_t piece_bytes) const {
+        const Reduced red = reduce(trimmed);
+        DfaProgram d;
+        Dfa2Program d2;
+        SampledTableStats st;
+        bool ok = false;
+        for (uint32_t budget = 2048; budget >= 64 && !ok; budget /= 2) {       // the largest table whose stride-2 form fits the LDS
+            if (!lower_dfa_sampled(red, text, pieces, piece_bytes, budget, d, &st)) return false;
+            ok = d.nstates <= 4096 && lower_dfa2(d, 1024, d2) && (size_t)d2.nstates * (d2.ncols | 1u) * 4 <= dev::kDfa2MaxTable;
+        }
+        if (!ok || d.escaped.empty()) return false;      // (no escape state: the closure closed the table - lower_dfa would have too)
+        std::lock_guard<std::mutex> lock(mu);
+        sampled_dfa = std::move(d); sampled_dfa2 = std::move(d2); sampled_stats = st;
+        sampled_ready.store(true, std::memory_order_release);
+        return true;
+    }
+    int sampled_tables(int device, dev::Dfa2Device *out) const {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = sampled_on_device.find(device);
+        if (it != sampled_on_device.end()) { *out = it->second.d; return RRX_OK; }
+        HIP_TRY(hipSetDevice(device));
+        std::vector<uint32_t> T2;
+        std::vector<uint16_t> P;
+        SampledOnDevice t;
+        build_dfa2_arrays_of(sampled_dfa2, {}, {}, T2, P, t.d);
+        const size_t pb = (P.size() * 2 + 15) & ~(size_t)15;
+        HIP_TRY(hipMalloc(&t.blob, pb + T2.size() * 4 + 16));
+        hipError_t e = hipMemcpy(t.blob, P.data(), P.size() * 2, hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMemcpy(static_cast<uint8_t *>(t.blob) + pb, T2.data(), T2.size() * 4, hipMemcpyHostToDevice);
+        if (e != hipSuccess) { (void)hipFree(t.blob); return hip_fail(e, "sampled table upload"); }
+        t.d.P = static_cast<const uint16_t *>(t.blob);
+        t.d.T2 = reinterpret_cast<const uint32_t *>(static_cast<uint8_t *>(t.blob) + pb);
+        sampled_on_device.emplace(device, t);
+        *out = t.d;
+        return RRX_OK;
+    }
     mutable std::vector<std::pair<int, void *>> t2_extra_blobs;      // tables uploaded again in the profiled order (device, blob)
     // The stride-2 tables as they go to the device, in the current order: T2 rows of `ncols | 1` entries (odd), R interleaved
     // copies, entry = LDS byte offset of the next row | lines << 16 | verdicts << 24; P = pair -> byte offset of its column.
     // `rows` / `cols`: an order to build for (else the current one: call with `mu` held)
     void build_dfa2_arrays(std::vector<uint32_t> &T2, std::vector<uint16_t> &P, dev::Dfa2Device &d, const std::vector<uint32_t> *rows = nullptr,
                            const std::vector<uint32_t> *cols = nullptr) const {
+        build_dfa2_arrays_of(dfa2, rows ? *rows : t2_row_slot, cols ? *cols : t2_col_slot, T2, P, d);
+    }
+    static void build_dfa2_arrays_of(const Dfa2Program &dfa2, const std::vector<uint32_t> &rs, const std::vector<uint32_t> &cs, std::vector<uint32_t> &T2,
+                                     std::vector<uint16_t> &P, dev::Dfa2Device &d) {
         const uint32_t D2 = dfa2.nstates, C2 = dfa2.ncols;
         const uint32_t s2 = C2 | 1u;
         uint32_t rep2 = 0;
         while (rep2 < 5 && (size_t)D2 * s2 * 4 * (2u << rep2) <= dev::kDfa2TableBudget && (size_t)C2 * 4 * (2u << rep2) <= 65535) rep2++;
         const uint32_t R2 = 1u << rep2;
         T2.assign((size_t)D2 * s2 * R2, 0);
-        const std::vector<uint32_t> &rs = rows ? *rows : t2_row_slot, &cs = cols ? *cols : t2_col_slot;
         const bool ordered = rs.size() == D2 && cs.size() == C2 && rs[0] == 0;
         auto row_slot = [&](uint32_t st) { return ordered ? rs[st] : st; };
         auto col_slot = [&](uint32_t col) { return ordered ? cs[col] : col; };
@@ -264,6 +320,8 @@ struct rrx_regex {
 
     ~rrx_regex() {
         t2_order.wait();
+        sampled_build.wait();
+        for (auto &kv : sampled_on_device) if (kv.second.blob) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.blob); }
         for (auto &kv : t2_extra_blobs) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second); }
         for (auto &kv : scratch) if (kv.second.p) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.p); }
         for (auto &kv : onepass_scratch) {
@@ -613,6 +671,7 @@ int rrx_compile_ex(const char *pattern, int engine, rrx_regex **out) {
     rrx_regex *re = new rrx_regex();
     try {
         re->pattern = pattern;
+        re->requested_engine = engine;
         re->ref = build_reference_automaton(re->pattern);
         re->trimmed = trim(re->ref);
         const Reduced red = reduce(re->trimmed);
@@ -700,9 +759,39 @@ int rrx_table_order(const rrx_regex *re, double *conflict_before, double *confli
     if (conflict_after) *conflict_after = profiled ? re->t2_order_stats.after : 0.0;
     return profiled ? 1 : st == TableOrderSearch::kRunning ? 2 : 0;   // 2: the search is running
 }
+int rrx_learn_table(rrx_regex *re, const void *text, size_t nbytes) {
+    if (!re || !text || nbytes < 2 || nbytes > ((size_t)1 << 30)) return fail(RRX_ERR_ARG, "a text sample of 2 bytes to 1 GiB");
+    if (!re->sampled_eligible()) return fail(RRX_ERR_UNSUPPORTED, "a sampled table serves automata that AUTO leaves on the NFA lane engine");
+    const uint8_t *p = static_cast<const uint8_t *>(text);
+    bool built = false;
+    if (!re->sampled_build.start([&]() { built = re->build_sampled(p, 1, (uint32_t)nbytes); }, /*background=*/false))
+        return fail(RRX_ERR_ARG, "the sampled table has been decided already");
+    return built ? RRX_OK : fail(RRX_ERR_UNSUPPORTED, "no sampled table fits the device for this automaton and text");
+}
+int rrx_sampled_table(const rrx_regex *re, uint32_t *table_states, uint32_t *open_transitions) {
+    const OnceTask::State st = re->sampled_build.state();
+    const bool ready = re->sampled_ready.load(std::memory_order_acquire);
+    std::lock_guard<std::mutex> lock(re->mu);
+    if (table_states) *table_states = ready ? re->sampled_dfa.nstates : 0;
+    if (open_transitions) *open_transitions = ready ? re->sampled_stats.open_transitions : 0;
+    return ready ? 1 : st == OnceTask::kRunning ? 2 : 0;
+}
+int rrx_sampled_escapes(const rrx_regex *re, int device, uint64_t *lines) {
+    if (!re || !lines) return fail(RRX_ERR_ARG, "null argument");
+    *lines = 0;
+    std::lock_guard<std::mutex> lock(re->onepass_mu);
+    auto it = re->sampled_counter.find(device);
+    if (it == re->sampled_counter.end() || !it->second) return RRX_OK;            // no sampled-table launch on this device yet
+    HIP_TRY(hipSetDevice(device));
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpy(&v, it->second, sizeof v, hipMemcpyDeviceToHost));            // (synchronous: behind everything queued on the device)
+    *lines = v;
+    return RRX_OK;
+}
 int rrx_set_option(rrx_regex *re, int option, int64_t value) {
     if (!re) return fail(RRX_ERR_ARG, "null argument");
     if (option == RRX_OPT_BACKGROUND_ORDER) { re->opt_background_order.store(value ? 1 : 0); return RRX_OK; }
+    if (option == RRX_OPT_SAMPLED_TABLE) { re->opt_sampled_table.store(value ? 1 : 0); return RRX_OK; }
     if (option == RRX_OPT_UNITS_PER_WORKGROUP) {
         if (value < 0 || value > 65536) return fail(RRX_ERR_ARG, "units per workgroup: 0 (off) or 16 ... 65536");
         re->opt_units_per_wg.store(value && value < 16 ? 16 : (int)value);
@@ -739,6 +828,22 @@ size_t rrx_program_words(const rrx_regex *re, int kind, uint32_t *out, size_t ca
         w = {re->dfa2.nstates, re->dfa2.ncols};
         w.insert(w.end(), re->t2_row_slot.begin(), re->t2_row_slot.end());
         w.insert(w.end(), re->t2_col_slot.begin(), re->t2_col_slot.end());
+    } else if (kind == RRX_PROGRAM_SAMPLED_DFA || kind == RRX_PROGRAM_SAMPLED_DFA2) {
+        if (!re->sampled_ready.load(std::memory_order_acquire)) return 0;
+        std::lock_guard<std::mutex> lock(re->mu);
+        if (kind == RRX_PROGRAM_SAMPLED_DFA) {              // the DFA layout, then the escaped flag per state
+            const DfaProgram &d = re->sampled_dfa;
+            w = {d.nstates, d.ncls, d.start, d.accepts_empty ? 1u : 0u};
+            for (int c = 0; c < 256; c++) w.push_back(d.cls[c]);
+            for (uint8_t a : d.accepting) w.push_back(a);
+            for (uint16_t n : d.next) w.push_back(n);
+            for (uint8_t e : d.escaped) w.push_back(e);
+        } else {                                            // the stride-2 layout (entries: next | result bits << 16 | verdict pairs << 24)
+            const Dfa2Program &d = re->sampled_dfa2;
+            w = {d.nstates, d.ncols, d.start, d.accepts_empty ? 1u : 0u};
+            for (uint16_t c : d.pair_col) w.push_back(c);
+            w.insert(w.end(), d.next2.begin(), d.next2.end());
+        }
     } else if (kind == RRX_ENGINE_DFA2 && re->has_dfa2) {
         const Dfa2Program &d = re->dfa2;
         w = {d.nstates, d.ncols, d.start, d.accepts_empty ? 1u : 0u};
@@ -846,6 +951,36 @@ void rrx_corpus_free(rrx_corpus *c) {
 
 size_t rrx_corpus_bitmap_words(const rrx_corpus *c) { return (c->nlines + 31) / 32; }
 
+// The batch entry on the sampled table: the stride-2 kernel with two result bits per line (accepted, escaped), the two bitmaps
+// taken apart, the escaped lines decided by the NFA lane engine.  Scratch (the wide bitmap, the escaped bitmap, a counter) is
+// the regex' event-ordered per-device buffer; everything is queued on `stream`, nothing is read back.
+static int match_corpus_sampled(const rrx_regex *re, const rrx_corpus *c, const DeviceTables *t, uint32_t *d_accept_bits, void *stream) {
+    dev::Dfa2Device d2;
+    int rc = re->sampled_tables(c->device, &d2);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t words = rrx_corpus_bitmap_words(c);
+    const size_t wide_bytes = (2 * words * sizeof(uint32_t) + 15) & ~(size_t)15, esc_bytes = (words * sizeof(uint32_t) + 15) & ~(size_t)15;
+    const size_t cap = std::max<size_t>(words / 2, 1024);                        // listed escaped lines: 1.5 % of the lines (then: the walk over the stripes)
+    std::lock_guard<std::mutex> lock(re->onepass_mu);
+    void *buf = nullptr;
+    rc = re->onepass_for(c->device, wide_bytes + esc_bytes + 16 + cap * sizeof(uint64_t), &buf, st);
+    if (rc) return rc;
+    uint32_t *wide = static_cast<uint32_t *>(buf);
+    uint32_t *escaped = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(buf) + wide_bytes);
+    unsigned long long *total = reinterpret_cast<unsigned long long *>(static_cast<uint8_t *>(buf) + wide_bytes + esc_bytes);
+    uint64_t *list = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(buf) + wide_bytes + esc_bytes + 16);
+    re->sampled_counter[c->device] = total;
+    hipError_t he = hipMemsetAsync(wide, 0, wide_bytes, st);                     // (the kernel merges words with atomic OR)
+    if (he == hipSuccess) he = hipMemsetAsync(total, 0, 16, st);
+    int e = he != hipSuccess ? (int)he : dev::match_stripes_dfa2_two_bit(d2, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, wide, stream);
+    if (!e) e = dev::split_two_bit(wide, c->nlines, d_accept_bits, escaped, total, list, cap, stream);
+    if (!e) e = dev::recheck_escaped_nfa(t->nfa, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, escaped, c->nlines, list, total, cap, d_accept_bits, stream);
+    const int rc2 = re->onepass_done(c->device, st);
+    if (e) return hip_fail((hipError_t)e, "sampled-table launch");
+    return rc2;
+}
+
 int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accept_bits, void *stream) {
     if (!re || !c || (c->nlines && !d_accept_bits)) return fail(RRX_ERR_ARG, "null argument");
     if (!re->t2_order.decided() && c->h_sample && !c->has_high) (void)re->decide_t2_order(c->h_sample, c->sample_lanes, kSampleBytes, /*now=*/false);
@@ -854,6 +989,17 @@ int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accep
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
     if (!c->nlines) return RRX_OK;
+    // the sampled table: its build starts at the first match against a corpus that carries a text sample (in the background;
+    // this launch and the next ones run on the NFA engine until it is in), and serves corpora without bytes >= 0x80
+    if (re->sampled_eligible() && re->opt_sampled_table.load() && !c->has_high) {
+        if (!re->sampled_build.decided() && c->h_sample) {
+            auto text = std::make_shared<std::vector<uint8_t>>(c->h_sample, c->h_sample + (size_t)c->sample_lanes * kSampleBytes);
+            const uint32_t pieces = c->sample_lanes;
+            (void)re->sampled_build.start([re, text, pieces]() { (void)re->build_sampled(text->data(), pieces, kSampleBytes); },
+                                          /*background=*/re->opt_background_order.load() != 0);
+        }
+        if (re->sampled_ready.load(std::memory_order_acquire)) return match_corpus_sampled(re, c, t, d_accept_bits, stream);
+    }
     // the kernel merges words with atomic OR: start from an all-zero bitmap
     HIP_TRY(hipMemsetAsync(d_accept_bits, 0, rrx_corpus_bitmap_words(c) * sizeof(uint32_t), (hipStream_t)stream));
     int e = re->engine == RRX_ENGINE_NFA_SPARSE

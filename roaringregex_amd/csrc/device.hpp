@@ -138,6 +138,19 @@ constexpr uint32_t kDfa2TableBudget = 30 * 1024;                      // T2 with
 
 int match_stripes_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
                        size_t nstripes, uint32_t *accept_bits, void *stream);
+// The sampled-table engine: the stride-2 kernel on a table with an ESCAPE state writes two bits per line into
+// `wide_bits` (2 x the accept bitmap, zeroed by the caller); split_two_bit takes them apart (every word of both outputs is
+// written) and counts the escaped lines; recheck_escaped_nfa lets the exact NFA lane engine decide those and ORs its accepts in.
+int match_stripes_dfa2_two_bit(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
+                               size_t nstripes, uint32_t *wide_bits, void *stream);
+// (`list`: the numbers of the escaped lines, `cap` entries; *escaped_total counts them all.  Up to `cap` escaped lines are decided
+// a lane per line, more by a walk over the stripes: both kernels are queued, each reads the count and the one that is not
+// needed ends at once.)
+int split_two_bit(const uint32_t *wide, size_t nlines, uint32_t *accept_bits, uint32_t *escaped_bits, unsigned long long *escaped_total, uint64_t *list,
+                  size_t cap, void *stream);
+int recheck_escaped_nfa(const NfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base, size_t nstripes,
+                        const uint32_t *escaped_bits, size_t nlines, const uint64_t *list, const unsigned long long *escaped_total, size_t cap,
+                        uint32_t *accept_bits, void *stream);
 // the same, stripes handed out in units of 64 inside the workgroup (units_per_wg of them per workgroup of 16 waves)
 int match_units_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
                      size_t nstripes, uint32_t *accept, uint32_t units_per_wg, void *stream);

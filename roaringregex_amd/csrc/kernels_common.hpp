@@ -107,6 +107,7 @@ struct ResultsT {
     typename std::conditional<STAGED, uint32_t, uint64_t>::type word;      // STAGED: relative to the first word of the window (a
                                            //   workgroup's text holds far fewer than 2^37 lines: 32 bits, one register less)
     bool drop_first;
+    uint32_t drop_mask = 1u;               // the result bits of one line (kernels that report two bits per line: 3)
     bool writer = true;                    // wave-cooperative kernels: every lane mirrors the bookkeeping, one writes
     uint32_t *__restrict__ out;            // STAGED: already advanced to the first word of the window
     uint32_t *stage = nullptr;
@@ -129,7 +130,7 @@ struct ResultsT {
         const int n = 31 - __clz((int)bits);
         if (n > 0) {                                         // n <= 31: callers flush before bits can overflow
             uint32_t rev = __brev(bits & ((1u << n) - 1u)) >> (32 - n);      // oldest line at bit 0
-            if (drop_first) { rev &= ~1u; drop_first = false; }
+            if (drop_first) { rev &= ~drop_mask; drop_first = false; }
             outw |= rev << fill;
             uint32_t nf = fill + (uint32_t)n;
             if (nf >= 32u) {                                 // then fill >= 1

@@ -251,6 +251,10 @@ RRX_NFA_PARTS(match_onepass_nfa,
 RRX_NFA_PARTS(match_extents_nfa,
               (const NfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim, uint8_t *accept, void *stream),
               (p, bytes, off, nitems, trim, accept, stream))
+RRX_NFA_PARTS(recheck_escaped_nfa,
+              (const NfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base, size_t nstripes, const uint32_t *escaped_bits,
+               size_t nlines, const uint64_t *list, const unsigned long long *escaped_total, size_t cap, uint32_t *accept_bits, void *stream),
+              (p, bytes, nbytes, stripe, stripe_base, nstripes, escaped_bits, nlines, list, escaped_total, cap, accept_bits, stream))
 RRX_NFA_PARTS(match_long_nfa,
               (const NfaDevice &p, const uint8_t *bytes, size_t nbytes, uint32_t chunk, uint32_t nchunks, void *scratch, uint8_t *accept, void *stream),
               (p, bytes, nbytes, chunk, nchunks, scratch, accept, stream))

@@ -282,7 +282,9 @@ __device__ __forceinline__ void feed_load(uint4 (&buf)[kRound / 16], const uint4
     }
 }
 // One stripe of one lane: lane-local state only (what the caller keeps across stripes is the engine, the window and `g`).
-template <bool ONEPASS, class PhaseHook, bool FEED_ASM = false>
+// KB: result bits per line - 1 (accepted), or 2 (accepted, ESCAPED: the sampled-table engine, whose table does not know every
+// transition; the table's line ends then shift two bits in, and everything that counts results counts bits).
+template <bool ONEPASS, class PhaseHook, bool FEED_ASM = false, int KB = 1>
 __device__ __forceinline__ void dfa2_stripe(const Dfa2 &eng, const size_t g, const uint64_t window_word, uint32_t *const stage, const uint32_t stage_words,
                                             const uint8_t *__restrict__ bytes, const size_t nbytes, const uint32_t stripe,
                                             const uint64_t *__restrict__ stripe_base, uint32_t *__restrict__ accept_bits,
@@ -298,8 +300,9 @@ __device__ __forceinline__ void dfa2_stripe(const Dfa2 &eng, const size_t g, con
     } else {
         const uint64_t my_base = stripe_base[g];
         fresh = (my_base & kFreshStripe) != 0;
-        res.begin_staged(line_of(my_base), window_word, !fresh, accept_bits, stage);
+        res.begin_staged(line_of(my_base) * KB, window_word, !fresh, accept_bits, stage);
         res.stage_words = stage_words;
+        res.drop_mask = (1u << KB) - 1u;
     }
     Dfa2::State st = fresh ? eng.fresh() : eng.skipping();
     auto clean = [](uint32_t w) -> uint32_t {                       // ONEPASS: bytes >= 0x80 -> 0x00
@@ -336,6 +339,7 @@ __device__ __forceinline__ void dfa2_stripe(const Dfa2 &eng, const size_t g, con
             } else {
                 eng.consume_dword(st, buf[i].x, res.bits);
                 eng.consume_dword(st, buf[i].y, res.bits);
+                if (KB == 2 && (res.bits >> 15)) res.flush();    // (two bits per line end: eight bytes can bring sixteen)
                 eng.consume_dword(st, buf[i].z, res.bits);
                 eng.consume_dword(st, buf[i].w, res.bits);
             }
@@ -365,14 +369,14 @@ __device__ __forceinline__ void dfa2_stripe(const Dfa2 &eng, const size_t g, con
         uint32_t lines, verdicts;
         eng.step2(st, byte_at(pos), byte_at(pos + 1), lines, verdicts);
         res.bits = (res.bits << lines) | verdicts;
-        if (res.bits >> 29) res.flush();
+        if (res.bits >> (31 - 2 * KB)) res.flush();
     }
     if (pos < my_end) {
         const uint32_t b = byte_at(pos);
         uint32_t lines, verdicts;
         eng.step2(st, b, '\n', lines, verdicts);
-        if (b == '\n') res.push(1, verdicts >> 1);
-        else { res.push(1, verdicts); closed_by_end_of_data = true; }
+        if (b == '\n') res.push(KB, verdicts >> KB);
+        else { res.push(KB, verdicts); closed_by_end_of_data = true; }
         pos++;
     }
     res.flush();
@@ -408,7 +412,7 @@ __device__ __forceinline__ void dfa2_stripe(const Dfa2 &eng, const size_t g, con
         }
         for (; pos + 2 <= nbytes && !lines; pos += 2) eng.step2(st, byte_at(pos), byte_at(pos + 1), lines, verdicts);
         if (!lines) eng.step2(st, pos < nbytes ? byte_at(pos) : '\n', '\n', lines, verdicts);   // end of data ends the line
-        res.push(1, lines == 2 ? verdicts >> 1 : verdicts);     // only the first line end of the pair is mine
+        res.push(KB, lines == 2 * KB ? verdicts >> KB : verdicts);     // only the first line end of the pair is mine
         followed = true;
     }
     res.finish();
@@ -418,7 +422,7 @@ __device__ __forceinline__ void dfa2_stripe(const Dfa2 &eng, const size_t g, con
     }
 }
 
-template <bool ONEPASS, class PhaseHook = NoPhaseHook>
+template <bool ONEPASS, class PhaseHook = NoPhaseHook, int KB = 1>
 __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t *__restrict__ bytes, size_t nbytes, uint32_t stripe,
                                           const uint64_t *__restrict__ stripe_base, uint32_t *__restrict__ accept_bits,
                                           uint32_t *__restrict__ counts, uint32_t *__restrict__ slabs, PhaseHook phase = PhaseHook()) {
@@ -441,8 +445,8 @@ __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t 
 
     const size_t g0 = (size_t)blockIdx.x * kThreads;
     uint64_t window_word = 0;
-    if (!ONEPASS) window_word = line_of(stripe_base[g0]) >> 5;       // the workgroup's first stripe exists: uniform load
-    dfa2_stripe<ONEPASS>(eng, g0 + threadIdx.x, window_word, stage, stage_words, bytes, nbytes, stripe, stripe_base, accept_bits, counts, slabs,
+    if (!ONEPASS) window_word = (line_of(stripe_base[g0]) * KB) >> 5;       // the workgroup's first stripe exists: uniform load
+    dfa2_stripe<ONEPASS, PhaseHook, false, KB>(eng, g0 + threadIdx.x, window_word, stage, stage_words, bytes, nbytes, stripe, stripe_base, accept_bits, counts, slabs,
                          gridDim.x * kThreads, phase);
     if (!ONEPASS) {
         // ---- write the window out: consecutive lanes, consecutive words (the atomics merge into whole lines in L2;
@@ -518,6 +522,12 @@ __global__ __launch_bounds__(kThreads) void match_stripes2_kernel(Dfa2Device pro
                                                                    uint32_t stripe, const uint64_t *__restrict__ stripe_base,
                                                                    uint32_t *__restrict__ accept_bits) {
     dfa2_body<false>(prog, bytes, nbytes, stripe, stripe_base, accept_bits, nullptr, nullptr);
+}
+// two result bits per line (accepted, escaped) into a bitmap of twice the size: the sampled-table engine's first pass
+__global__ __launch_bounds__(kThreads) void match_stripes2_two_bit_kernel(Dfa2Device prog, const uint8_t *__restrict__ bytes, size_t nbytes,
+                                                                           uint32_t stripe, const uint64_t *__restrict__ stripe_base,
+                                                                           uint32_t *__restrict__ wide_bits) {
+    dfa2_body<false, NoPhaseHook, 2>(prog, bytes, nbytes, stripe, stripe_base, wide_bits, nullptr, nullptr);
 }
 __global__ __launch_bounds__(kThreads) void match_stripes2_onepass_kernel(Dfa2Device prog, const uint8_t *__restrict__ bytes, size_t nbytes,
                                                                            uint32_t stripe, uint32_t *__restrict__ counts,
@@ -1325,6 +1335,86 @@ int match_stripes_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes,
     if (Dfa2::lds_bytes(p) > kDfa2MaxTable) return (int)hipErrorInvalidValue;
     size_t blocks = (nstripes + kThreads - 1) / kThreads;
     hipLaunchKernelGGL(match_stripes2_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept);
+    return (int)hipGetLastError();
+}
+// ---- the sampled-table engine's second step: the two-bit bitmap (bit 2i = line i accepted, bit 2i + 1 = line i ended in the
+// ESCAPE state) taken apart into the accept bitmap - every word written, nothing to clear beforehand - and the bitmap of the
+// escaped lines, which the exact engine then decides (recheck_escaped: kernels_nfa.inc); their number is added up on the side.
+// `list` receives the numbers of the escaped lines (in no order; `cap` entries: what does not fit is counted all the same, and
+// recheck_escaped then walks the stripes instead).  A workgroup collects its lines in LDS and reserves room in the list a
+// thousand at a time: one atomic per escaped line - or per wave that met one - on the one counter cost a millisecond at
+// 400 000 escaped lines.
+__global__ __launch_bounds__(256) void split_two_bit_kernel(const uint32_t *__restrict__ wide, size_t words, uint32_t *__restrict__ accept_bits,
+                                                             uint32_t *__restrict__ escaped_bits, unsigned long long *__restrict__ escaped_total,
+                                                             uint64_t *__restrict__ list, size_t cap) {
+    constexpr uint32_t kLocal = 4096, kFlushAt = kLocal - 256 * 8;      // (a turn adds at most 256 x 32 lines: see the two-step append below)
+    __shared__ uint64_t local[kLocal];
+    __shared__ uint32_t nlocal;
+    __shared__ unsigned long long flush_base;
+    if (threadIdx.x == 0) nlocal = 0;
+    __syncthreads();
+    auto even_bits = [](uint32_t x) -> uint32_t {                   // bits 0, 2, 4, ... packed into the low half
+        x &= 0x55555555u;
+        x = (x | x >> 1) & 0x33333333u;
+        x = (x | x >> 2) & 0x0f0f0f0fu;
+        x = (x | x >> 4) & 0x00ff00ffu;
+        return (x | x >> 8) & 0xffffu;
+    };
+    auto flush = [&]() {                                             // whole workgroup; nlocal is stable here
+        __syncthreads();
+        const uint32_t n = nlocal;
+        if (n) {
+            if (threadIdx.x == 0) flush_base = atomicAdd(escaped_total, (unsigned long long)n);
+            __syncthreads();
+            const unsigned long long base = flush_base;
+            for (uint32_t i = threadIdx.x; i < n; i += 256) if (base + i < cap) list[base + i] = local[i];
+            __syncthreads();
+            if (threadIdx.x == 0) nlocal = 0;
+        }
+        __syncthreads();
+    };
+    const size_t turns = (words + (size_t)gridDim.x * 256 - 1) / ((size_t)gridDim.x * 256);       // the same for every lane: the flushes are collective
+    for (size_t it = 0; it < turns; it++) {
+        const size_t w = (it * gridDim.x + blockIdx.x) * 256 + threadIdx.x;
+        uint32_t esc = 0;
+        if (w < words) {
+            const uint2 v = reinterpret_cast<const uint2 *>(wide)[w];
+            accept_bits[w] = even_bits(v.x) | even_bits(v.y) << 16;
+            esc = even_bits(v.x >> 1) | even_bits(v.y >> 1) << 16;
+            escaped_bits[w] = esc;
+        }
+        // append my escaped lines, eight at a time (so that a turn never overruns the local buffer between two flushes)
+        while (__syncthreads_or(esc != 0)) {
+            uint32_t take = 0;
+            for (uint32_t k = 0, m = esc; k < 8 && m; k++) { take |= m & (0u - m); m &= m - 1; }
+            const uint32_t c = (uint32_t)__popc(take);
+            if (c) {
+                uint32_t at = atomicAdd(&nlocal, c);
+                for (uint32_t m = take; m; m &= m - 1) local[at++] = (uint64_t)w * 32 + (uint32_t)(__ffs((int)m) - 1);
+            }
+            esc &= ~take;
+            __syncthreads();
+            if (nlocal > kFlushAt) flush();
+        }
+    }
+    flush();
+}
+int match_stripes_dfa2_two_bit(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
+                               size_t nstripes, uint32_t *wide_bits, void *stream) {
+    if (!nstripes) return 0;
+    if (Dfa2::lds_bytes(p) > kDfa2MaxTable) return (int)hipErrorInvalidValue;
+    size_t blocks = (nstripes + kThreads - 1) / kThreads;
+    hipLaunchKernelGGL(match_stripes2_two_bit_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, wide_bits);
+    return (int)hipGetLastError();
+}
+int split_two_bit(const uint32_t *wide, size_t nlines, uint32_t *accept_bits, uint32_t *escaped_bits, unsigned long long *escaped_total, uint64_t *list,
+                  size_t cap, void *stream) {
+    const size_t words = (nlines + 31) / 32;
+    if (!words) return 0;
+    size_t blocks = (words + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(split_two_bit_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, wide, words, accept_bits, escaped_bits, escaped_total,
+                       list, cap);
     return (int)hipGetLastError();
 }
 int match_units_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,

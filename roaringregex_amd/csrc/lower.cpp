@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <memory>
 #include <queue>
 #include <unordered_map>
 
@@ -840,59 +841,12 @@ bool lower_nfa(const Reduced &red, uint32_t max_bits, NfaProgram &p, bool allow_
 }
 
 // ------------------------------------------------------------------------------------------ DFA lowering
-// Subset construction + minimisation.  `sticky`: the initial node stays in every set and no byte kills (the
-// automaton of "anything, then the pattern": search_dfas below); class 0 then gets a real column.
-static bool subset_construct(const Reduced &red, uint32_t max_states, bool sticky, DfaProgram &d) {
-    d = DfaProgram();
-    std::memcpy(d.cls, red.cls, sizeof d.cls);
-    d.ncls = red.ncls;
-    if (red.nodes.empty()) {
-        d.nstates = 1; d.start = 0; d.accepting = {0}; d.next.assign(d.ncls, 0);
-        return true;
-    }
-    const std::vector<Node> &nodes = red.nodes;
-    const uint32_t K = red.ncls, N = (uint32_t)nodes.size();
-    // in-class membership of every node: bit k of member[u] words
-    std::vector<std::vector<uint8_t>> enters(N, std::vector<uint8_t>(K, 0));
-    for (uint32_t u = 1; u < N; u++) for (uint32_t k = 1; k < K; k++) enters[u][k] = nodes[u].label.has(red.cls_rep[k]);
-    std::map<std::vector<uint32_t>, uint32_t> ids;
-    std::vector<std::vector<uint32_t>> sets;
-    std::vector<uint32_t> nxt;                          // raw [state][class]
-    size_t budget = (size_t)24 << 20;                   // total set elements: give up early on exploding automata
-    auto intern = [&](std::vector<uint32_t> &&v) -> int64_t {
-        auto it = ids.find(v);
-        if (it != ids.end()) return it->second;
-        if (sets.size() >= max_states || v.size() > budget) return -1;
-        budget -= v.size();
-        uint32_t id = (uint32_t)sets.size();
-        ids.emplace(v, id);
-        sets.push_back(std::move(v));
-        return id;
-    };
-    intern({});                                         // 0 = dead (unreachable when sticky)
-    intern({0});                                        // 1 = start: the initial node
-    std::vector<uint32_t> all, seen_at(N, 0);
-    uint32_t epoch = 0;
-    for (uint32_t cur = 0; cur < sets.size(); cur++) {
-        nxt.resize((size_t)(cur + 1) * K, 0);
-        all.clear();                                    // the union of the follow sets: each node once, then sorted
-        epoch++;
-        for (uint32_t u : sets[cur]) for (uint32_t v : nodes[u].follow) if (seen_at[v] != epoch) { seen_at[v] = epoch; all.push_back(v); }
-        std::sort(all.begin(), all.end());
-        for (uint32_t k = sticky ? 0 : 1; k < K; k++) {
-            std::vector<uint32_t> v;
-            if (sticky && cur != 0) v.push_back(0);     // node 0 sorts first; it is entered on nothing
-            if (k) for (uint32_t x : all) if (enters[x][k]) v.push_back(x);
-            int64_t id = intern(std::move(v));
-            if (id < 0) return false;
-            nxt[(size_t)cur * K + k] = (uint32_t)id;
-        }
-    }
-    const uint32_t D = (uint32_t)sets.size();
-    std::vector<uint8_t> acc(D, 0);
-    for (uint32_t i = 0; i < D; i++) for (uint32_t u : sets[i]) if (nodes[u].fin) { acc[i] = 1; break; }
-    // ---- minimisation: Hopcroft's partition refinement (the "recompute every signature until nothing splits" form took one
-    // round per state on a chain - a{1,n} is n rounds over n states: 0.45 s at n = 2400, minutes at 16000)
+// Minimisation (Hopcroft's partition refinement) of a complete table over K classes and its renumbering.  kind[i]: 0 = rejecting,
+// 1 = accepting, 2 = the ESCAPE state of a sampled table (kept apart from the dead state it would otherwise merge with).
+// State 0 is the dead state, state 1 the start.  (The "recompute every signature until nothing splits" form took one round per
+// state on a chain - a{1,n} is n rounds over n states: 0.45 s at n = 2400, minutes at 16000.)
+static bool minimise_into(const std::vector<uint32_t> &nxt, const std::vector<uint8_t> &kind, const uint32_t K, DfaProgram &d) {
+    const uint32_t D = (uint32_t)kind.size();
     std::vector<uint32_t> block(D);
     uint32_t count = 0;
     {
@@ -905,15 +859,14 @@ static bool subset_construct(const Reduced &red, uint32_t max_states, bool stick
             for (uint32_t i = 0; i < D; i++)
                 for (uint32_t k = 0; k < K; k++) inv[(size_t)k * D + fill[(size_t)k * (D + 1) + nxt[(size_t)i * K + k]]++] = i;
         }
-        // the partition: elems holds the states block by block; a block is elems[lo[b] .. hi[b])
+        // the partition: elems holds the states block by block; a block is elems[lo[b] .. hi[b]).  It starts as the kinds present.
         std::vector<uint32_t> elems(D), loc(D), lo, hi, marked;
         {
-            uint32_t n0 = 0;
-            for (uint32_t i = 0; i < D; i++) if (!acc[i]) n0++;
-            uint32_t p0 = 0, p1 = n0;
-            for (uint32_t i = 0; i < D; i++) { const uint32_t at = acc[i] ? p1++ : p0++; elems[at] = i; loc[i] = at; }
-            if (n0) { lo.push_back(0); hi.push_back(n0); }
-            if (n0 < D) { lo.push_back(n0); hi.push_back(D); }
+            uint32_t n_of[3] = {0, 0, 0}, at[3];
+            for (uint32_t i = 0; i < D; i++) n_of[kind[i]]++;
+            at[0] = 0; at[1] = n_of[0]; at[2] = n_of[0] + n_of[1];
+            for (int q = 0; q < 3; q++) if (n_of[q]) { lo.push_back(at[q]); hi.push_back(at[q] + n_of[q]); }
+            for (uint32_t i = 0; i < D; i++) { const uint32_t p = at[kind[i]]++; elems[p] = i; loc[i] = p; }
             for (uint32_t b = 0; b < lo.size(); b++) for (uint32_t q = lo[b]; q < hi[b]; q++) block[elems[q]] = b;
         }
         marked.assign(lo.size(), 0);
@@ -924,8 +877,9 @@ static bool subset_construct(const Reduced &red, uint32_t max_states, bool stick
             if (!queued[(size_t)b * K + k]) { queued[(size_t)b * K + k] = 1; work.emplace_back(b, k); }
         };
         {
-            const uint32_t small = lo.size() == 2 && hi[1] - lo[1] < hi[0] - lo[0] ? 1 : 0;
-            if (lo.size() == 2) for (uint32_t k = 0; k < K; k++) enqueue(small, k);
+            uint32_t largest = 0;                       // every starting block but the largest is a splitter
+            for (uint32_t b = 1; b < lo.size(); b++) if (hi[b] - lo[b] > hi[largest] - lo[largest]) largest = b;
+            for (uint32_t b = 0; b < lo.size(); b++) if (b != largest) for (uint32_t k = 0; k < K; k++) enqueue(b, k);
         }
         std::vector<uint32_t> touched, splitter;
         while (!work.empty()) {
@@ -981,16 +935,166 @@ static bool subset_construct(const Reduced &red, uint32_t max_states, bool stick
     d.nstates = count;
     d.accepting.assign(count, 0);
     d.next.assign((size_t)count * K, 0);
+    bool any_escape = false;
+    for (uint32_t i = 0; i < D; i++) any_escape = any_escape || kind[i] == 2;
+    if (any_escape) d.escaped.assign(count, 0);
     for (uint32_t i = 0; i < D; i++) {
         uint32_t b = (uint32_t)id[block[i]];
-        d.accepting[b] = acc[i];
+        d.accepting[b] = kind[i] == 1;
+        if (kind[i] == 2) d.escaped[b] = 1;
         for (uint32_t k = 0; k < K; k++) d.next[(size_t)b * K + k] = (uint16_t)id[block[nxt[(size_t)i * K + k]]];
     }
     d.start = (uint32_t)id[block[1]];
     d.accepts_empty = d.accepting[d.start];
     return true;
 }
+// Subset construction + minimisation.  `sticky`: the initial node stays in every set and no byte kills (the
+// automaton of "anything, then the pattern": search_dfas below); class 0 then gets a real column.
+static bool subset_construct(const Reduced &red, uint32_t max_states, bool sticky, DfaProgram &d) {
+    d = DfaProgram();
+    std::memcpy(d.cls, red.cls, sizeof d.cls);
+    d.ncls = red.ncls;
+    if (red.nodes.empty()) {
+        d.nstates = 1; d.start = 0; d.accepting = {0}; d.next.assign(d.ncls, 0);
+        return true;
+    }
+    const std::vector<Node> &nodes = red.nodes;
+    const uint32_t K = red.ncls, N = (uint32_t)nodes.size();
+    // in-class membership of every node: bit k of member[u] words
+    std::vector<std::vector<uint8_t>> enters(N, std::vector<uint8_t>(K, 0));
+    for (uint32_t u = 1; u < N; u++) for (uint32_t k = 1; k < K; k++) enters[u][k] = nodes[u].label.has(red.cls_rep[k]);
+    std::map<std::vector<uint32_t>, uint32_t> ids;
+    std::vector<std::vector<uint32_t>> sets;
+    std::vector<uint32_t> nxt;                          // raw [state][class]
+    size_t budget = (size_t)24 << 20;                   // total set elements: give up early on exploding automata
+    auto intern = [&](std::vector<uint32_t> &&v) -> int64_t {
+        auto it = ids.find(v);
+        if (it != ids.end()) return it->second;
+        if (sets.size() >= max_states || v.size() > budget) return -1;
+        budget -= v.size();
+        uint32_t id = (uint32_t)sets.size();
+        ids.emplace(v, id);
+        sets.push_back(std::move(v));
+        return id;
+    };
+    intern({});                                         // 0 = dead (unreachable when sticky)
+    intern({0});                                        // 1 = start: the initial node
+    std::vector<uint32_t> all, seen_at(N, 0);
+    uint32_t epoch = 0;
+    for (uint32_t cur = 0; cur < sets.size(); cur++) {
+        nxt.resize((size_t)(cur + 1) * K, 0);
+        all.clear();                                    // the union of the follow sets: each node once, then sorted
+        epoch++;
+        for (uint32_t u : sets[cur]) for (uint32_t v : nodes[u].follow) if (seen_at[v] != epoch) { seen_at[v] = epoch; all.push_back(v); }
+        std::sort(all.begin(), all.end());
+        for (uint32_t k = sticky ? 0 : 1; k < K; k++) {
+            std::vector<uint32_t> v;
+            if (sticky && cur != 0) v.push_back(0);     // node 0 sorts first; it is entered on nothing
+            if (k) for (uint32_t x : all) if (enters[x][k]) v.push_back(x);
+            int64_t id = intern(std::move(v));
+            if (id < 0) return false;
+            nxt[(size_t)cur * K + k] = (uint32_t)id;
+        }
+    }
+    const uint32_t D = (uint32_t)sets.size();
+    std::vector<uint8_t> kind(D, 0);
+    for (uint32_t i = 0; i < D; i++) for (uint32_t u : sets[i]) if (nodes[u].fin) { kind[i] = 1; break; }
+    return minimise_into(nxt, kind, K, d);
+}
 bool lower_dfa(const Reduced &red, uint32_t max_states, DfaProgram &d) { return subset_construct(red, max_states, false, d); }
+
+bool lower_dfa_sampled(const Reduced &red, const uint8_t *sample, uint32_t pieces, uint32_t piece_bytes, uint32_t max_states, DfaProgram &d,
+                       SampledTableStats *stats) {
+    d = DfaProgram();
+    std::memcpy(d.cls, red.cls, sizeof d.cls);
+    d.ncls = red.ncls;
+    if (red.nodes.empty() || !sample || max_states < 4) return false;
+    const std::vector<Node> &nodes = red.nodes;
+    const uint32_t K = red.ncls, N = (uint32_t)nodes.size();
+    std::vector<std::vector<uint8_t>> enters(N, std::vector<uint8_t>(K, 0));
+    for (uint32_t u = 1; u < N; u++) for (uint32_t k = 1; k < K; k++) enters[u][k] = nodes[u].label.has(red.cls_rep[k]);
+    constexpr uint32_t kOpen = UINT32_MAX, kEscape = UINT32_MAX - 1;
+    std::map<std::vector<uint32_t>, uint32_t> ids;
+    std::vector<std::vector<uint32_t>> sets, unions;    // unions[i]: the union of the follow sets of set i (made when first needed)
+    std::vector<uint8_t> has_union;
+    std::vector<uint32_t> nxt;                          // [set][class]: set id, kOpen, kEscape
+    const uint32_t budget = max_states - 1;             // (one row is the escape state)
+    size_t elements = (size_t)8 << 20;
+    auto add_set = [&](std::vector<uint32_t> &&v) -> uint32_t {
+        const uint32_t id = (uint32_t)sets.size();
+        ids.emplace(v, id);
+        elements -= std::min(elements, v.size());
+        sets.push_back(std::move(v));
+        unions.emplace_back(); has_union.push_back(0);
+        nxt.resize((size_t)(id + 1) * K, kOpen);
+        nxt[(size_t)id * K] = 0;                        // class 0: nothing moves - the dead set
+        return id;
+    };
+    add_set({});                                        // 0 = dead
+    for (uint32_t k = 0; k < K; k++) nxt[k] = 0;
+    add_set({0});                                       // 1 = start
+    std::vector<uint32_t> seen_at(N, 0);
+    uint32_t epoch = 0;
+    auto resolve = [&](uint32_t cur, uint32_t k) -> uint32_t {      // the transition (cur, k): an id, or kEscape when the budget is spent
+        uint32_t &slot = nxt[(size_t)cur * K + k];
+        if (slot != kOpen) return slot;
+        if (!has_union[cur]) {
+            epoch++;
+            for (uint32_t u : sets[cur]) for (uint32_t v : nodes[u].follow) if (seen_at[v] != epoch) { seen_at[v] = epoch; unions[cur].push_back(v); }
+            std::sort(unions[cur].begin(), unions[cur].end());
+            has_union[cur] = 1;
+        }
+        std::vector<uint32_t> v;
+        for (uint32_t x : unions[cur]) if (enters[x][k]) v.push_back(x);
+        auto it = ids.find(v);
+        uint32_t to;
+        if (it != ids.end()) to = it->second;
+        else if (sets.size() < budget && v.size() <= elements) to = add_set(std::move(v));
+        else to = kEscape;
+        return nxt[(size_t)cur * K + k] = to;           // (add_set may have moved nxt: index again)
+    };
+    SampledTableStats st;
+    // ---- the sets the sample reaches
+    for (uint32_t p = 0; p < pieces; p++) {
+        const uint8_t *t = sample + (size_t)p * piece_bytes;
+        uint32_t i = 0;
+        while (i < piece_bytes && t[i] != '\n') i++;    // a piece begins inside somebody's line: enter at the first line start
+        i++;
+        uint32_t cur = 1;
+        for (; i < piece_bytes; i++) {
+            const uint8_t c = t[i];
+            if (c == '\n') { cur = 1; continue; }
+            if (cur == kEscape) continue;               // until the end of the line
+            st.sample_bytes_stepped++;
+            cur = resolve(cur, c < 0x80 ? red.cls[c] : 0);
+            if (cur == kEscape) st.sample_escapes++;
+        }
+    }
+    st.sets_from_sample = (uint32_t)sets.size();
+    if (!st.sample_bytes_stepped) return false;
+    // ---- closure: the transitions still open, breadth-first over the sets in the order they were found
+    for (uint32_t cur = 0; cur < sets.size(); cur++)
+        for (uint32_t k = 1; k < K; k++) (void)resolve(cur, k);
+    st.sets_from_closure = (uint32_t)sets.size() - st.sets_from_sample;
+    // ---- the table: the escape state last; it leaves on class 0 only (whatever the set was, that byte kills it: a plain reject)
+    const uint32_t D = (uint32_t)sets.size() + 1, esc = D - 1;
+    std::vector<uint32_t> full((size_t)D * K);
+    std::vector<uint8_t> kind(D, 0);
+    for (uint32_t i = 0; i + 1 < D; i++) {
+        for (uint32_t u : sets[i]) if (nodes[u].fin) { kind[i] = 1; break; }
+        for (uint32_t k = 0; k < K; k++) {
+            const uint32_t to = nxt[(size_t)i * K + k];
+            if (to == kEscape) st.open_transitions++;
+            full[(size_t)i * K + k] = to == kEscape ? esc : to;
+        }
+    }
+    kind[esc] = 2;
+    full[(size_t)esc * K] = 0;
+    for (uint32_t k = 1; k < K; k++) full[(size_t)esc * K + k] = esc;
+    if (stats) *stats = st;
+    if (!st.open_transitions) kind[esc] = 0;            // the closure closed everything: an ordinary table (the escape row is unreachable)
+    return minimise_into(full, kind, K, d);
+}
 
 // The pattern read right to left, as a graph of the same shape: node w stands for "a byte of label(w) has just been
 // consumed backwards and the automaton is in the predecessors of w"; it is final iff the initial node is a predecessor.
@@ -1072,8 +1176,10 @@ bool lower_dfa2(const DfaProgram &d, uint32_t max_cols, Dfa2Program &o) {
     o = Dfa2Program();
     const uint32_t D = d.nstates, K = d.ncls, NL = K;            // symbols 0..K-1 = byte classes, K = '\n'
     o.nstates = D; o.start = d.start; o.accepts_empty = d.accepts_empty;
+    const bool two_bit = !d.escaped.empty();                     // a line end reports (accepted, escaped)
+    const uint32_t kb = two_bit ? 2u : 1u;
     auto step = [&](uint32_t s, uint32_t sym, uint32_t &line, uint32_t &verdict) -> uint32_t {
-        if (sym == NL) { line = 1; verdict = d.accepting[s]; return d.start; }
+        if (sym == NL) { line = 1; verdict = two_bit ? (uint32_t)d.accepting[s] << 1 | d.escaped[s] : d.accepting[s]; return d.start; }
         line = 0; verdict = 0;
         return d.next[(size_t)s * K + sym];
     };
@@ -1087,8 +1193,8 @@ bool lower_dfa2(const DfaProgram &d, uint32_t max_cols, Dfa2Program &o) {
                 uint32_t l1, v1, l2, v2;
                 const uint32_t s1 = step(s, a, l1, v1);
                 const uint32_t s2 = step(s1, b, l2, v2);
-                const uint32_t verdicts = (l1 && l2) ? (v1 << 1 | v2) : l1 ? v1 : v2;
-                col[s] = s2 | (l1 + l2) << 16 | verdicts << 24;
+                const uint32_t verdicts = (l1 && l2) ? (v1 << kb | v2) : l1 ? v1 : v2;
+                col[s] = s2 | ((l1 + l2) * kb) << 16 | verdicts << 24;
             }
             auto it = cols.find(col);
             if (it == cols.end()) {
@@ -1225,28 +1331,35 @@ Dfa2OrderStats order_dfa2(const Dfa2Program &d, const uint8_t *sample, uint32_t 
     return st;
 }
 
-// ------------------------------------------------------------------------------------------ the search beside the caller
-bool TableOrderSearch::start(const Dfa2Program &d, std::vector<uint8_t> sample, uint32_t lanes, uint32_t bytes_per_lane, bool background, Apply apply) {
+// ------------------------------------------------------------------------------------------ work beside the caller
+bool OnceTask::start(std::function<void()> job, bool background) {
     std::unique_lock<std::mutex> lock(mu_);        // held from the decision to the thread being in place: wait() sees both or neither
     int expected = kIdle;
     if (!state_.compare_exchange_strong(expected, kRunning, std::memory_order_acq_rel)) return false;
-    auto body = [this, &d, lanes, bytes_per_lane](std::vector<uint8_t> text, Apply fn) {
-        std::vector<uint32_t> rows, cols;
-        const Dfa2OrderStats st = order_dfa2(d, text.data(), lanes, bytes_per_lane, rows, cols);
-        fn(std::move(rows), std::move(cols), st);
+    auto body = [this](std::function<void()> fn) {
+        fn();
         state_.store(kDone, std::memory_order_release);
     };
-    if (!background) { lock.unlock(); body(std::move(sample), std::move(apply)); return true; }
-    thread_ = std::thread(body, std::move(sample), std::move(apply));
+    if (!background) { lock.unlock(); body(std::move(job)); return true; }
+    thread_ = std::thread(body, std::move(job));
     return true;
 }
-bool TableOrderSearch::skip() {
+bool OnceTask::skip() {
     int expected = kIdle;
     return state_.compare_exchange_strong(expected, kSkipped, std::memory_order_acq_rel);
 }
-void TableOrderSearch::wait() {
+void OnceTask::wait() {
     std::lock_guard<std::mutex> lock(mu_);
     if (thread_.joinable()) thread_.join();
+}
+bool TableOrderSearch::start(const Dfa2Program &d, std::vector<uint8_t> sample, uint32_t lanes, uint32_t bytes_per_lane, bool background, Apply apply) {
+    // (shared_ptr: std::function wants a copyable callable)
+    auto text = std::make_shared<std::vector<uint8_t>>(std::move(sample));
+    return OnceTask::start([&d, text, lanes, bytes_per_lane, apply]() {
+        std::vector<uint32_t> rows, cols;
+        const Dfa2OrderStats st = order_dfa2(d, text->data(), lanes, bytes_per_lane, rows, cols);
+        apply(std::move(rows), std::move(cols), st);
+    }, background);
 }
 
 }  // namespace rrx

@@ -71,6 +71,7 @@ struct DfaProgram {
     uint32_t ncls = 0;                      // = Trimmed::ncls
     uint32_t start = 0;
     std::vector<uint8_t> accepting;         // per state
+    std::vector<uint8_t> escaped;           // sampled tables only (else empty): the ESCAPE state - "the table does not know"
     std::vector<uint16_t> next;             // [state][class]
     uint8_t cls[256];
     bool accepts_empty = false;
@@ -84,7 +85,8 @@ struct Dfa2Program {
     std::vector<uint32_t> next2;            // [nstates][ncols]: next state | lines ended (0..2) << 16 | verdicts << 24
     bool accepts_empty = false;             //   (verdicts: oldest line highest)
 };
-// Returns false if there are more than max_cols distinct pair columns.
+// Returns false if there are more than max_cols distinct pair columns.  A sampled table (d.escaped) yields the TWO-BIT form:
+// a line end shifts two result bits in, (accepted, escaped), the counts in byte 2 of an entry are bit counts.
 bool lower_dfa2(const DfaProgram &d, uint32_t max_cols, Dfa2Program &out);
 // Profile-guided ORDER of the stride-2 table's rows and columns in LDS.  The table's entry for (state s, pair column c) sits at
 // word row_slot[s] * (ncols | 1) + col_slot[c], i.e. in LDS bank (row_slot[s] * (ncols | 1) + col_slot[c]) mod 32: the order
@@ -97,29 +99,32 @@ struct Dfa2OrderStats { double before = 0, after = 0; uint32_t half_waves = 0, e
 Dfa2OrderStats order_dfa2(const Dfa2Program &d, const uint8_t *sample, uint32_t lanes, uint32_t bytes_per_lane,
                           std::vector<uint32_t> &row_slot, std::vector<uint32_t> &col_slot);
 
-// The state machine around order_dfa2 when it runs beside the caller (host only: no device call in here; the owner passes what
-// to do with the result as `apply`).  One search per object, decided once: start() or skip() moves kIdle on, everything
-// else only READS the atomic state - the std::thread is touched by its owner alone (start under `mu_`, wait()).
-class TableOrderSearch {
+// A piece of host work that is decided ONCE per object and may run beside the caller (host only: no device call in here).
+// start() or skip() moves kIdle on, everything else only READS the atomic state - the std::thread is touched by its owner
+// alone (start under `mu_`, wait()).  The job runs in the deciding caller's thread or in a thread of its own (joined by
+// wait() / the destructor); the state becomes kDone when it returns.
+class OnceTask {
 public:
     enum State { kIdle = 0, kRunning = 1, kDone = 2, kSkipped = 3 };
-    using Apply = std::function<void(std::vector<uint32_t> &&row_slot, std::vector<uint32_t> &&col_slot, const Dfa2OrderStats &)>;
-    TableOrderSearch() = default;
-    TableOrderSearch(const TableOrderSearch &) = delete;
-    TableOrderSearch &operator=(const TableOrderSearch &) = delete;
-    ~TableOrderSearch() { wait(); }
+    OnceTask() = default;
+    OnceTask(const OnceTask &) = delete;
+    OnceTask &operator=(const OnceTask &) = delete;
+    ~OnceTask() { wait(); }
     State state() const { return (State)state_.load(std::memory_order_acquire); }
     bool decided() const { return state() != kIdle; }
-    // false: decided before (by another caller).  background: the search runs in a thread of its own (joined by wait() / the
-    // destructor), else in the caller's.  `d` must outlive the search; `apply` runs in the searching thread, then the state
-    // becomes kDone.
-    bool start(const Dfa2Program &d, std::vector<uint8_t> sample, uint32_t lanes, uint32_t bytes_per_lane, bool background, Apply apply);
+    bool start(std::function<void()> job, bool background);       // false: decided before (by another caller)
     bool skip();                // kIdle -> kSkipped; false: decided before
-    void wait();                // returns when no search is running any more
+    void wait();                // returns when no job of this object is running in a thread of its own any more
 private:
     std::atomic<int> state_{kIdle};
     std::mutex mu_;             // guards thread_
     std::thread thread_;
+};
+// The order search of the stride-2 table (order_dfa2) as such a task: `d` must outlive it; `apply` runs in the searching thread.
+class TableOrderSearch : public OnceTask {
+public:
+    using Apply = std::function<void(std::vector<uint32_t> &&row_slot, std::vector<uint32_t> &&col_slot, const Dfa2OrderStats &)>;
+    bool start(const Dfa2Program &d, std::vector<uint8_t> sample, uint32_t lanes, uint32_t bytes_per_lane, bool background, Apply apply);
 };
 
 // The trimmed automaton re-expressed over "positions" (a state split by the character set it is entered on; node 0
@@ -143,6 +148,15 @@ Reduced reduce(const Trimmed &t);
 bool lower_nfa(const Reduced &r, uint32_t max_bits, NfaProgram &out, bool allow_carry = true, bool gaps = false);
 // Returns false if subset construction exceeds max_states.
 bool lower_dfa(const Reduced &r, uint32_t max_states, DfaProgram &out);
+// The table of an automaton whose subset construction explodes, over the sets a TEXT SAMPLE reaches (README.md:18-21:
+// the live sets met on real text are few).  The sets are interned as the sample is stepped (`pieces` pieces of `piece_bytes` bytes,
+// each entered at its first line start), then every transition still open is closed breadth-first while `max_states` allows;
+// what stays open leads to the ESCAPE state (absorbing until the end of the line, neither accepting nor rejecting: d.escaped).
+// A line that ends outside ESCAPE has exactly the reference's verdict; a line that ends in it must be decided by an exact
+// engine.  Returns false if nothing could be built (an empty automaton; a sample without a line start).
+struct SampledTableStats { uint32_t sets_from_sample = 0, sets_from_closure = 0, open_transitions = 0; uint64_t sample_bytes_stepped = 0, sample_escapes = 0; };
+bool lower_dfa_sampled(const Reduced &r, const uint8_t *sample, uint32_t pieces, uint32_t piece_bytes, uint32_t max_states, DfaProgram &out,
+                       SampledTableStats *stats = nullptr);
 
 // Search (the reference has acceptance only).  fwd: the DFA of "any bytes, then the pattern" - no
 // byte kills it, it is accepting exactly at the positions where some match ends.  rev: the DFA of the pattern read

@@ -111,6 +111,49 @@ class Dfa2Replay:
         return out[:-1] if drop_last else out
 
 
+class SampledReplay:
+    """The sampled table (rrx_program_words kinds 12 and 13): a DFA with an ESCAPE state - [D, K, start, accepts_empty, cls[256],
+    accepting[D], next[D][K], escaped[D]] - and its stride-2 form, whose line ends carry TWO result bits (accepted, escaped).
+    verdict(line) -> 1 / 0 / None (the table does not know); match_lines2(data) -> the same per line through the stride-2 form."""
+
+    def __init__(self, dfa_words, dfa2_words):
+        w = np.asarray(dfa_words, dtype=np.int64)
+        self.D, self.K, self.start = int(w[0]), int(w[1]), int(w[2])
+        self.cls = w[4:260]
+        self.acc = w[260:260 + self.D]
+        self.next = w[260 + self.D:260 + self.D + self.D * self.K].reshape(self.D, self.K)
+        self.esc = w[260 + self.D + self.D * self.K:260 + 2 * self.D + self.D * self.K]
+        w2 = np.asarray(dfa2_words, dtype=np.int64)
+        self.D2, self.C2, self.start2 = int(w2[0]), int(w2[1]), int(w2[2])
+        self.pair_col = w2[4:4 + 16384]
+        self.next2 = w2[4 + 16384:].reshape(self.D2, self.C2)
+
+    def verdict(self, line):
+        st = self.start
+        for c in line:
+            st = int(self.next[st, self.cls[c] if c < 128 else 0])
+        return None if self.esc[st] else int(self.acc[st])
+
+    def match_lines2(self, data):
+        seq = bytearray(data)
+        if not seq:
+            return []
+        if seq[-1] != 10:
+            seq.append(10)
+        drop_last = len(seq) % 2 == 1
+        if drop_last:
+            seq.append(10)
+        out, st = [], self.start2
+        for i in range(0, len(seq), 2):
+            e = int(self.next2[st, self.pair_col[seq[i] * 128 + seq[i + 1]]])
+            st, nbits, bits = e & 0xffff, (e >> 16) & 0xff, e >> 24
+            assert nbits % 2 == 0
+            for k in range(nbits // 2):
+                pair = (bits >> (nbits - 2 - 2 * k)) & 3
+                out.append(None if pair & 1 else pair >> 1)
+        return out[:-1] if drop_last else out
+
+
 class SearchReplay:
     """The two search tables (rrx_program_words kinds 6 and 7, DFA layout) replayed the way search_stripes_kernel runs
     them: forward until accepting = smallest match end; then backwards from there, last accepting position = smallest

@@ -436,6 +436,82 @@ def test_units_handed_out_inside_the_workgroup_change_no_result():
         plain.set_units_per_workgroup(1 << 20)
 
 
+def test_sampled_table_for_automata_that_do_not_determinise():
+    """U2(x|y)*x(x|y){30} and (U2)|(x|y)*x(x|y){30}: 2^31 state sets on x/y text, so AUTO leaves them on the NFA lane engine; the sets
+    URL text reaches are a hundred.  rrx_learn_table interns those into a table with an ESCAPE state; rrx_match_corpus then runs the
+    stride-2 kernel with two result bits per line and the NFA engine decides the escaped lines.  Exact against the oracle on text like
+    the sample (no line escapes), on text built to escape on most lines (x/y tails the sample never showed), on a mix, at three
+    stripe sizes, with empty lines, lines longer than a stripe and no final newline - and equal to the NFA engine alone."""
+    import synth
+    rng = random.Random(77)
+    url = synth.corpus("url", 3, 3 << 20)
+    lines = url.tobytes().split(b"\n")[:-1]
+    tail = lambda: bytes(rng.choice(b"xy") for _ in range(rng.randint(0, 80)))
+    # (what escapes: x/y runs the sample never showed - behind a valid url for the first pattern, on their own for the second)
+    hostile = [ln + tail() for ln in lines[:6000]] + [tail() for _ in range(3000)] + [b"", b"x" * 31, b"y" * 31, b"x" * 5000 + b"y" * 30,
+                                                                                      lines[0] + b"x" * 9000, lines[2] + b"\x00x"]
+    dirty = hostile[:500] + [b"\x80" + lines[1], lines[3] + b"\xc3\xa9x"]         # bytes >= 0x80: the corpus takes the NFA engine
+    mixed = lines[:20000]
+    for k in range(0, len(mixed), 37):
+        mixed[k] = mixed[k] + tail()
+    for pattern in (U2 + "(x|y)*x(x|y){30}", "(" + U2 + ")|(x|y)*x(x|y){30}"):
+        o = OracleRegex(pattern)
+        r = rr.RRegex(pattern)
+        assert r.engine_name == "nfa-shift-and" and r.sampled_table is None
+        plain = rr.RRegex(pattern)
+        plain.set_sampled_table(False)
+        states, open_tr = r.learn_table(url[:1 << 16])
+        assert 20 < states < 2000 and open_tr > 0 and r.sampled_table == (states, open_tr)
+        for name, ls, tailnl in (("like the sample", lines[:30000], b"\n"), ("hostile", hostile, b""), ("dirty", dirty, b"\n"), ("mixed", mixed, b"\n")):
+            data = np.frombuffer(b"\n".join(ls) + tailnl, dtype=np.uint8)
+            clean = not (data >= 0x80).any()
+            want = o.match_lines(data)
+            dev = torch.from_numpy(data.copy()).cuda()
+            for stripe in (512, 4096, 0):
+                corpus = rr.Corpus(dev, stripe=stripe)
+                got = r.match_corpus(corpus).cpu().numpy()
+                assert got.shape == want.shape and (got == want).all(), (pattern[-24:], name, stripe, np.nonzero(got != want)[0][:5])
+                assert torch.equal(plain.match_corpus_bits(corpus), r.match_corpus_bits(corpus)), (name, stripe, clean)
+                if clean and name == "hostile":
+                    assert r.sampled_escapes() > 1000, "the hostile text is meant to escape"
+                if name == "like the sample":
+                    assert r.sampled_escapes() < len(ls) // 50
+        assert plain.sampled_table is None
+    # an automaton that determinises has no use for it; neither has a forced engine
+    with pytest.raises(rr.RRegexError):
+        rr.RRegex(U2).learn_table(url[:4096])
+    with pytest.raises(rr.RRegexError):
+        rr.RRegex(U2 + "(x|y)*x(x|y){30}", rr.ENGINE_NFA).learn_table(url[:4096])
+
+
+def test_sampled_table_learnt_from_the_first_large_corpus():
+    """Without rrx_learn_table: the first rrx_match_corpus against a corpus of 64 MiB or more starts the build from the corpus' own
+    sample in the background; launches race the swap, every one of them exact (the NFA engine before, the table after)."""
+    import synth
+    import time
+    pattern = "(" + U2 + ")|(x|y)*x(x|y){30}"
+    data = synth.corpus("url", 5, 96 << 20)
+    dev = torch.from_numpy(data).cuda()
+    corpus = rr.Corpus(dev)
+    plain = rr.RRegex(pattern)
+    plain.set_sampled_table(False)
+    ref = plain.match_corpus_bits(corpus).clone()
+    head = data[:1 << 20]
+    cut = int(np.flatnonzero(head == 10)[-1]) + 1
+    want = OracleRegex(pattern).match_lines(head[:cut])
+    got = plain.match_corpus(corpus).cpu().numpy()
+    assert (got[:len(want)] == want).all() and 0 < want.sum() < len(want)
+    r = rr.RRegex(pattern)
+    t0 = time.time()
+    launches = 0
+    while r.sampled_table is None and time.time() - t0 < 30:
+        assert torch.equal(r.match_corpus_bits(corpus), ref)
+        launches += 1
+    assert r.sampled_table is not None, launches
+    for _ in range(3):
+        assert torch.equal(r.match_corpus_bits(corpus), ref)
+
+
 def test_table_order_from_a_caller_sample_after_the_tables_are_up():
     """rrx_order_table on a regex whose tables are already on the device (it matched a small corpus first): the stride-2 arrays
     are uploaded again in the new order and swapped in; results before and after are the oracle's."""

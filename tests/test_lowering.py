@@ -2,11 +2,13 @@
 oracle row by row), and both device programs must keep its language (replayed in Python).  No GPU needed."""
 import random
 
+import numpy as np
+
 import pytest
 
 import roaringregex_amd as rr
 from patterns import EMAIL, K1000, K1000_CONTAINS, KAT, U2, random_pattern, strings_near
-from program_replay import Dfa2Replay, DfaReplay, NfaReplay
+from program_replay import Dfa2Replay, DfaReplay, NfaReplay, SampledReplay
 from pyoracle import OracleError, OracleRegex
 
 
@@ -521,3 +523,47 @@ def test_budget_refusal_is_an_error_not_a_hang():
     assert b"work budget" in L.rrx_last_error()
     with pytest.raises(rr.RRegexError, match="too many states"):   # RRX_ERR_PATTERN: beyond the front end's 65536 states
         rr.RRegex("(a|b)*a(a|b){20000}")
+
+
+def test_sampled_table_decides_exactly_or_not_at_all():
+    """lower_dfa_sampled (README.md:18-21: the live sets met on real text are few): U2(x|y)*x(x|y){30} and
+    (U2)|(x|y)*x(x|y){30} do not determinise (2^31 sets on x/y text) and AUTO leaves them on the NFA lane engine; a table over the
+    sets a URL text sample reaches has about a hundred states.  Every line it DECIDES has the oracle's verdict, the others end in
+    the ESCAPE state; text like the sample is decided throughout, x/y tails escape; the stride-2 form with two result bits per
+    line end says the same line by line."""
+    import synth
+    rng = random.Random(9)
+    url = synth.corpus("url", 3, 2 << 20)
+    lines = url.tobytes().split(b"\n")[:-1]
+    for pattern in (U2 + "(x|y)*x(x|y){30}", "(" + U2 + ")|(x|y)*x(x|y){30}"):
+        o = OracleRegex(pattern)
+        r = rr.RRegex(pattern)
+        assert r.engine == rr.ENGINE_NFA and r.sampled_table is None and r.program(rr.PROGRAM_SAMPLED_DFA) is None
+        states, open_tr = r.learn_table(url[:1 << 16])
+        assert 20 < states < 2000 and open_tr > 0
+        with pytest.raises(rr.RRegexError):
+            r.learn_table(url[:1 << 16])                           # decided once
+        rep = SampledReplay(r.program(rr.PROGRAM_SAMPLED_DFA), r.program(rr.PROGRAM_SAMPLED_DFA2))
+        assert int(rep.esc.sum()) == 1 and not rep.acc[np.nonzero(rep.esc)[0][0]]
+        like = lines[2000:6000]                                      # (beyond the 64 KiB the table was learnt from)
+        # what escapes: x/y runs the sample never showed - behind a VALID url for the first pattern, on their own for the second
+        valid = [ln for ln in lines[6000:9000] if OracleRegex(U2).accepts(ln.decode("latin-1"))][:300]
+        tails = [ln + bytes(rng.choice(b"xy") for _ in range(rng.randint(20, 80))) for ln in valid] + \
+                [bytes(rng.choice(b"xy") for _ in range(rng.randint(1, 80))) for _ in range(300)] + [b"", b"x" * 31, b"xy" * 40]
+        decided = escaped = 0
+        for ln in like + tails:
+            v = rep.verdict(ln)
+            if v is None:
+                escaped += 1
+            else:
+                decided += 1
+                assert v == int(o.accepts(ln.decode("latin-1"))), (pattern[-20:], ln)
+        assert sum(rep.verdict(ln) is None for ln in like) <= len(like) // 50, "text like the sample hardly escapes (x/y runs in a path do)"
+        assert escaped > 50 and decided > 4000
+        data = b"\n".join(like[:600] + tails[:80]) + b"\n"
+        assert rep.match_lines2(data) == [rep.verdict(ln) for ln in like[:600] + tails[:80]]
+    # an automaton that determinises has no use for a sampled table; a forced engine is left alone
+    with pytest.raises(rr.RRegexError, match="AUTO"):
+        rr.RRegex(U2).learn_table(url[:4096])
+    with pytest.raises(rr.RRegexError, match="AUTO"):
+        rr.RRegex(U2 + "(x|y)*x(x|y){30}", rr.ENGINE_NFA).learn_table(url[:4096])
