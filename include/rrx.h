@@ -73,12 +73,15 @@ int         rrx_order_table(rrx_regex *re, const void *sample, uint32_t lanes, u
  * allocate device memory behind the caller's back for the profiled table order above - the table then stays as numbered
  * unless the caller orders it himself with rrx_order_table (which runs in the calling thread).  Set it before the regex'
  * first rrx_match_corpus; a search that is already running is not stopped.  RRX_ERR_ARG for an unknown option.          */
+/* RRX_OPT_FLUSH_SLOTS (default 0 = automatic): the stride-2 batch kernel lets all lanes flush their result bits together every
+ * `value` slots (16 bytes of a lane's text; 1, 2, 4, 8, 16 or 32); automatic: from the corpus' mean line length, about eight
+ * line ends per period.  A tuning knob: results never depend on it.                                                       */
 /* RRX_OPT_SAMPLED_TABLE (default 1): 0 keeps an automaton whose subset construction explodes on the NFA lane engine for every
  * launch (see rrx_learn_table).                                                                                          */
 /* RRX_OPT_UNITS_PER_WORKGROUP (default 0 = off): the stride-2 batch kernel hands its stripes out in units of 64 inside the
  * workgroup, `value` (16 ... 65536) of them per workgroup of 16 waves, a wave taking its next unit from a counter in LDS.
  * Same results; measured no faster than one stripe per lane on any config (profiles/r04_unit_handout_ab.txt).           */
-enum { RRX_OPT_BACKGROUND_ORDER = 1, RRX_OPT_UNITS_PER_WORKGROUP = 2, RRX_OPT_SAMPLED_TABLE = 3 };
+enum { RRX_OPT_BACKGROUND_ORDER = 1, RRX_OPT_UNITS_PER_WORKGROUP = 2, RRX_OPT_SAMPLED_TABLE = 3, RRX_OPT_FLUSH_SLOTS = 4 };
 int         rrx_set_option(rrx_regex *re, int option, int64_t value);
 /* The SAMPLED TABLE (an automaton that does not determinise - AUTO leaves it on the NFA lane engine - over text whose live sets
  * are few, README.md:18-21): the state sets a text sample reaches are interned into a table, every transition the sample and a

@@ -24,6 +24,7 @@ PROGRAM_SAMPLED_DFA2 = 13
 OPT_BACKGROUND_ORDER = 1
 OPT_UNITS_PER_WORKGROUP = 2
 OPT_SAMPLED_TABLE = 3
+OPT_FLUSH_SLOTS = 4
 
 # every symbol include/rrx.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = (
@@ -488,6 +489,10 @@ class RRegex:
     @property
     def sampled_table_pending(self):
         return _L.rrx_sampled_table(self._h, None, None) == 2
+
+    def set_flush_slots(self, slots):
+        """rrx_set_option(RRX_OPT_FLUSH_SLOTS): 0 = automatic, or 1 ... 32 slots between two common flushes of the stride-2 kernel."""
+        _check(_L.rrx_set_option(self._h, OPT_FLUSH_SLOTS, int(slots)))
 
     def set_units_per_workgroup(self, units):
         """rrx_set_option(RRX_OPT_UNITS_PER_WORKGROUP): the stride-2 batch kernel hands its stripes out in units of 64 inside

@@ -115,6 +115,7 @@ struct rrx_regex {
     std::atomic<int> opt_background_order{1};            // RRX_OPT_BACKGROUND_ORDER
     std::atomic<int> opt_units_per_wg{0};                // RRX_OPT_UNITS_PER_WORKGROUP (0: one stripe per lane and launch)
     std::atomic<int> opt_sampled_table{1};               // RRX_OPT_SAMPLED_TABLE
+    std::atomic<int> opt_flush_slots{0};                 // RRX_OPT_FLUSH_SLOTS (0: from the corpus' mean line length)
     // ---- the sampled table: AUTO ended on the NFA lane engine because the subset construction explodes; the sets a
     // text sample reaches are interned into a table with an ESCAPE state, the batch entry runs the stride-2 kernel on it (two result
     // bits per line) and lets the NFA engine decide the lines that escaped.  Built once: by the first rrx_match_corpus against a
@@ -791,6 +792,11 @@ int rrx_sampled_escapes(const rrx_regex *re, int device, uint64_t *lines) {
 int rrx_set_option(rrx_regex *re, int option, int64_t value) {
     if (!re) return fail(RRX_ERR_ARG, "null argument");
     if (option == RRX_OPT_BACKGROUND_ORDER) { re->opt_background_order.store(value ? 1 : 0); return RRX_OK; }
+    if (option == RRX_OPT_FLUSH_SLOTS) {
+        if (value != 0 && value != 1 && value != 2 && value != 4 && value != 8 && value != 16 && value != 32) return fail(RRX_ERR_ARG, "flush period: 0 (automatic) or 1, 2, 4, 8, 16, 32 slots");
+        re->opt_flush_slots.store((int)value);
+        return RRX_OK;
+    }
     if (option == RRX_OPT_SAMPLED_TABLE) { re->opt_sampled_table.store(value ? 1 : 0); return RRX_OK; }
     if (option == RRX_OPT_UNITS_PER_WORKGROUP) {
         if (value < 0 || value > 65536) return fail(RRX_ERR_ARG, "units per workgroup: 0 (off) or 16 ... 65536");
@@ -1013,7 +1019,8 @@ int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accep
             : (re->has_dfa2 && !c->has_high)
                 ? (re->opt_units_per_wg.load()
                        ? dev::match_units_dfa2(re->dfa2_device(t), c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, (uint32_t)re->opt_units_per_wg.load(), stream)
-                       : dev::match_stripes_dfa2(re->dfa2_device(t), c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream))
+                       : dev::match_stripes_dfa2(re->dfa2_device(t), c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream,
+                                                 re->opt_flush_slots.load() ? (uint32_t)re->opt_flush_slots.load() - 1u : dev::flush_mask_for(c->nbytes, c->nlines)))
                 : dev::match_stripes_dfa(t->line, c->has_high, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, d_accept_bits, stream);
     if (e) return hip_fail((hipError_t)e, "match_stripes launch");
     return RRX_OK;

@@ -136,8 +136,9 @@ constexpr uint32_t kDfa2RegionBytes = 46 * 1024;
 constexpr uint32_t kDfa2MaxTable = kDfa2RegionBytes - 4 * 1024;       // a table this large leaves a 4 KiB window
 constexpr uint32_t kDfa2TableBudget = 30 * 1024;                      // T2 with its copies
 
+uint32_t flush_mask_for(size_t nbytes, size_t nlines);      // the stride-2 kernel's common flush period from the mean line length
 int match_stripes_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
-                       size_t nstripes, uint32_t *accept_bits, void *stream);
+                       size_t nstripes, uint32_t *accept, void *stream, uint32_t flush_mask = 31u);
 // The sampled-table engine: the stride-2 kernel on a table with an ESCAPE state writes two bits per line into
 // `wide_bits` (2 x the accept bitmap, zeroed by the caller); split_two_bit takes them apart (every word of both outputs is
 // written) and counts the escaped lines; recheck_escaped_nfa lets the exact NFA lane engine decide those and ORs its accepts in.

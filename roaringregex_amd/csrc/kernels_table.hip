@@ -288,7 +288,8 @@ template <bool ONEPASS, class PhaseHook, bool FEED_ASM = false, int KB = 1>
 __device__ __forceinline__ void dfa2_stripe(const Dfa2 &eng, const size_t g, const uint64_t window_word, uint32_t *const stage, const uint32_t stage_words,
                                             const uint8_t *__restrict__ bytes, const size_t nbytes, const uint32_t stripe,
                                             const uint64_t *__restrict__ stripe_base, uint32_t *__restrict__ accept_bits,
-                                            uint32_t *__restrict__ counts, uint32_t *__restrict__ slabs, const uint32_t slab_row, PhaseHook &phase) {
+                                            uint32_t *__restrict__ counts, uint32_t *__restrict__ slabs, const uint32_t slab_row, PhaseHook &phase,
+                                            const uint32_t flush_mask = 31u) {
     const size_t start = g * (size_t)stripe;
     if (start < nbytes) {                                            // (no early return: the write-out below is collective)
     const size_t stripe_end = start + stripe;
@@ -343,9 +344,13 @@ __device__ __forceinline__ void dfa2_stripe(const Dfa2 &eng, const size_t g, con
                 eng.consume_dword(st, buf[i].z, res.bits);
                 eng.consume_dword(st, buf[i].w, res.bits);
             }
-            if (res.bits >> 15) res.flush();                 // <= 16 more results fit before the next check
+            // All lanes flush TOGETHER every (flush_mask + 1) slots - a period the host picks from the corpus' mean line length so
+            // that about eight results gather in it (short lines: every other slot; 512 bytes for long ones).  The overflow
+            // check behind it is for the lanes that meet far more: left to it alone, lanes overflow at different times and the
+            // wave walks the flush path at nearly every slot (5-byte lines: +1.25 VALU per byte).
+            if ((((uint32_t)r * kSlots + (uint32_t)i) & flush_mask) == flush_mask) res.flush();
+            else if (res.bits >> 15) res.flush();            // <= 16 more results fit before the next check
         }
-        if ((r & 3) == 3) res.flush();
         if (r + 1 < rounds) {
             feed_load<FEED_ASM>(buf, src + (r + 1) * kSlots);
         } else {
@@ -425,7 +430,8 @@ __device__ __forceinline__ void dfa2_stripe(const Dfa2 &eng, const size_t g, con
 template <bool ONEPASS, class PhaseHook = NoPhaseHook, int KB = 1>
 __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t *__restrict__ bytes, size_t nbytes, uint32_t stripe,
                                           const uint64_t *__restrict__ stripe_base, uint32_t *__restrict__ accept_bits,
-                                          uint32_t *__restrict__ counts, uint32_t *__restrict__ slabs, PhaseHook phase = PhaseHook()) {
+                                          uint32_t *__restrict__ counts, uint32_t *__restrict__ slabs, PhaseHook phase = PhaseHook(),
+                                          uint32_t flush_mask = 31u) {
     phase(kPhaseEntry);
     // T2 first: its entries hold 16-bit LDS addresses; the result window takes what T2 leaves of its region (16 KiB and
     // more for tables up to 30 KiB, 4 KiB at least).  The arrays are static, so P's base is a link-time constant.
@@ -447,7 +453,7 @@ __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t 
     uint64_t window_word = 0;
     if (!ONEPASS) window_word = (line_of(stripe_base[g0]) * KB) >> 5;       // the workgroup's first stripe exists: uniform load
     dfa2_stripe<ONEPASS, PhaseHook, false, KB>(eng, g0 + threadIdx.x, window_word, stage, stage_words, bytes, nbytes, stripe, stripe_base, accept_bits, counts, slabs,
-                         gridDim.x * kThreads, phase);
+                         gridDim.x * kThreads, phase, flush_mask);
     if (!ONEPASS) {
         // ---- write the window out: consecutive lanes, consecutive words (the atomics merge into whole lines in L2;
         // the first and the last word of the window are shared with the neighbouring workgroups)
@@ -520,8 +526,8 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(8, 8))
 }
 __global__ __launch_bounds__(kThreads) void match_stripes2_kernel(Dfa2Device prog, const uint8_t *__restrict__ bytes, size_t nbytes,
                                                                    uint32_t stripe, const uint64_t *__restrict__ stripe_base,
-                                                                   uint32_t *__restrict__ accept_bits) {
-    dfa2_body<false>(prog, bytes, nbytes, stripe, stripe_base, accept_bits, nullptr, nullptr);
+                                                                   uint32_t *__restrict__ accept_bits, uint32_t flush_mask) {
+    dfa2_body<false>(prog, bytes, nbytes, stripe, stripe_base, accept_bits, nullptr, nullptr, NoPhaseHook(), flush_mask);
 }
 // two result bits per line (accepted, escaped) into a bitmap of twice the size: the sampled-table engine's first pass
 __global__ __launch_bounds__(kThreads) void match_stripes2_two_bit_kernel(Dfa2Device prog, const uint8_t *__restrict__ bytes, size_t nbytes,
@@ -1329,12 +1335,19 @@ int match_stripes_dfa(const LineDfaDevice &p, bool clamp_high, const uint8_t *by
     return GO(false, false);
 #undef GO
 }
+// slots (16 bytes of a lane's text) between two flushes of ALL lanes, minus one: about sixteen line ends per period
+uint32_t flush_mask_for(size_t nbytes, size_t nlines) {
+    const size_t avg = nlines ? nbytes / nlines : nbytes;
+    uint32_t slots = 1;
+    while (slots < 32 && (size_t)slots * 2 * 16 <= avg * 16) slots *= 2;      // (measured: profiles/r04_flush_period_ab.txt)
+    return slots - 1;
+}
 int match_stripes_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
-                       size_t nstripes, uint32_t *accept, void *stream) {
+                       size_t nstripes, uint32_t *accept, void *stream, uint32_t flush_mask) {
     if (!nstripes) return 0;
     if (Dfa2::lds_bytes(p) > kDfa2MaxTable) return (int)hipErrorInvalidValue;
     size_t blocks = (nstripes + kThreads - 1) / kThreads;
-    hipLaunchKernelGGL(match_stripes2_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept);
+    hipLaunchKernelGGL(match_stripes2_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept, flush_mask);
     return (int)hipGetLastError();
 }
 // ---- the sampled-table engine's second step: the two-bit bitmap (bit 2i = line i accepted, bit 2i + 1 = line i ended in the
