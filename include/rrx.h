@@ -110,6 +110,11 @@ int         rrx_accepts_empty(const rrx_regex *re); /* Processor::operator*() on
 #define RRX_PROGRAM_SEARCH_LINE 9  /* the forward table as the stripe-wise search kernel runs it: [nrows, ncols, start row,
                                       SKIP row, column of byte[256], entry[nrows][ncols]], entry = next row | '\n' << 16 |
                                       hit << 17 | match-starts-at-the-line-start << 18 (0 words: form not available)   */
+#define RRX_PROGRAM_SEARCH_LINE2 14 /* its stride-2 form, what the kernel steps (two bytes per dependent lookup): [nrows, ncols, start row,
+                                      SKIP row, layout (1: LDS, 2: HBM/L2, 0: the stripe-wise kernel is not used), column of the byte
+                                      pair[128][128], first[nrows][ncols], all[nrows][ncols]], entry = next row | events << 24, events =
+                                      flags of the first byte << 2 | of the second; flags 1 '\n', 2 hit, 3 hit that starts at the restart
+                                      point; first: a hit leads to SKIP, all: back to the start row                         */
 #define RRX_PROGRAM_SAMPLED_DFA 12  /* the sampled table (rrx_learn_table): the DFA layout, then escaped[nstates] (1: the ESCAPE state) */
 #define RRX_PROGRAM_SAMPLED_DFA2 13 /* its stride-2 form as the kernel runs it: the DFA2 layout, byte 2 of an entry = RESULT BITS shifted
                                        in (two per line end: accepted, escaped), byte 3 = those bits                          */

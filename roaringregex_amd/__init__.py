@@ -18,6 +18,7 @@ PROGRAM_SEARCH_FWD, PROGRAM_SEARCH_REV = 6, 7          # rrx_program_words kinds
 ENGINE_NFA_BLOCK = 8
 ENGINE_NFA_SPARSE = 10
 PROGRAM_SEARCH_LINE = 9
+PROGRAM_SEARCH_LINE2 = 14
 PROGRAM_DFA2_ORDER = 11
 PROGRAM_SAMPLED_DFA = 12
 PROGRAM_SAMPLED_DFA2 = 13

@@ -263,6 +263,9 @@ struct rrx_regex {
     mutable int search_state = 0;        // 0 = not built, 1 = built, -1 = does not fit
     mutable DfaProgram search_fwd, search_rev;
     mutable SearchLineProgram search_line;  // stripe-wise form (nrows = 0: not built)
+    mutable SearchLine2Program search_line2;    // its stride-2 form, what the stripe-wise kernel runs (nrows = 0: not built)
+    mutable dev::SearchChunkDevice chunk_proto; // its layout on the device, without the pointers (nrows = 0: the line-per-lane kernels)
+    mutable bool search_lanes_ok = false;       // the plain forward + reverse tables fit the line-per-lane kernels' LDS
     mutable std::map<int, SearchTablesOnDevice> search_on_device;
     mutable std::map<int, ItemsTableOnDevice> items_on_device;
     // Scratch of the single-string entries (rrx_match_string / rrx_match_cstr): one grow-only device buffer per device,
@@ -374,11 +377,36 @@ struct rrx_regex {
             const Reduced red = reduce(trimmed);
             const bool ok = search_dfas(red, kMaxSubsetStates, search_fwd, search_rev);
             DfaProgram anchored;
-            if (!(ok && lower_dfa(red, kMaxSubsetStates, anchored) && lower_search_line(search_fwd, anchored, 16383, search_line)))
+            if (!(ok && lower_dfa(red, kMaxSubsetStates, anchored) && lower_search_line(search_fwd, anchored, 65534, search_line)))
                 search_line = SearchLineProgram();
+            search_line2 = SearchLine2Program();
+            if (search_line.nrows) {
+                uint32_t column[256];
+                for (int c = 0; c < 256; c++) column[c] = c == '\n' ? search_line.ncols - 1 : search_fwd.cls[c];
+                if (!lower_search_line2(search_line, column, 16383, search_line2)) search_line2 = SearchLine2Program();
+            }
+            // the stripe-wise kernel's layout of that table: LDS if it fits beside the reverse table, the job pools and a result
+            // window, else HBM/L2 (device.hpp: SearchChunkDevice); neither: the line-per-lane kernels, if THEIR tables fit
+            chunk_proto = dev::SearchChunkDevice();
+            const SearchLine2Program &s2 = search_line2;
+            if (s2.nrows && search_fwd.ncls < 128) {
+                dev::SearchChunkDevice c;
+                c.nrows = s2.nrows; c.ncols2 = s2.ncols; c.start_row = s2.start; c.skip_row = s2.skip;
+                c.nr = search_rev.nstates; c.ncls = search_fwd.ncls; c.start_r = search_rev.start;
+                uint32_t rb = (2 * s2.ncols + 3) & ~3u;
+                if (((rb >> 2) & 1u) == 0) rb += 4;                           // an odd number of dwords per row: rows spread over the LDS banks
+                c.row_bytes = rb; c.base_row = (dev::kSearchP8Bytes + rb - 1) / rb; c.in_global = 0;
+                bool fits = s2.ncols <= 127 && c.base_row + s2.nrows <= 4096 && dev::search_chunks_lds_bytes(c) <= dev::kSearchChunkLdsBudget;
+                if (!fits) {
+                    c.row_bytes = 0; c.base_row = 0; c.in_global = 1;
+                    fits = dev::search_chunks_lds_bytes(c) <= dev::kSearchChunkLdsBudget;      // (the reverse table has no global form)
+                }
+                if (fits) chunk_proto = c;
+            }
             dev::SearchDevice probe;
             probe.nf = search_fwd.nstates; probe.nr = search_rev.nstates; probe.ncls = search_fwd.ncls;
-            search_state = ok && dev::search_lds_bytes(probe) <= dev::kSearchLdsBudget && probe.nf <= 32767 && probe.nr <= 32767 ? 1 : -1;
+            search_lanes_ok = ok && dev::search_lds_bytes(probe) <= dev::kSearchLdsBudget && probe.nf <= 32767 && probe.nr <= 32767;
+            search_state = ok && (search_lanes_ok || chunk_proto.nrows) ? 1 : -1;
         }
         return search_state == 1 ? RRX_OK : fail(RRX_ERR_UNSUPPORTED, "search tables too large for the device (forward + reverse DFA must fit 64 KiB of LDS)");
     }
@@ -395,35 +423,50 @@ struct rrx_regex {
         const size_t oNF = put(search_fwd.next.data(), search_fwd.next.size() * 2), oNR = put(search_rev.next.data(), search_rev.next.size() * 2);
         const size_t oAF = put(search_fwd.accepting.data(), search_fwd.accepting.size()), oAR = put(search_rev.accepting.data(), search_rev.accepting.size());
         SearchTablesOnDevice t;
-        // The stripe-wise form (lower_search_line): row indices become byte offsets, flags move to byte 2 of the entry:
-        // bit 0 = '\n', bit 1 = hit, and for a hit bit 0 = anchored (flag values 1 = '\n', 2 = hit, 3 = hit, match starts
-        // at the line start).
-        size_t oTL = 0, oTA = 0, oC4 = 0, oRV = 0;
+        // The stripe-wise form: the line-mode product table in its stride-2 form (lower_search_line2), laid out for LDS (16-bit
+        // entries, a byte-wide pair table) when it fits beside the reverse table, the job pools and a result window, and for
+        // HBM/L2 (32-bit entries, a 16-bit pair table in LDS) when it does not (device.hpp: SearchChunkDevice).
+        size_t oP = 0, oT = 0, oTA = 0, oRV = 0;
         const uint32_t K = search_fwd.ncls, NR = search_rev.nstates;
-        const bool line_form = search_line.nrows && (size_t)search_line.nrows * search_line.ncols * 4 <= 65535 - 512 && K < 128;
+        const SearchLine2Program &s2 = search_line2;
+        const bool line_form = chunk_proto.nrows != 0;
+        t.chunk = chunk_proto;
+        if (line_form && !t.chunk.in_global) {
+            const uint32_t rb = t.chunk.row_bytes, br = t.chunk.base_row;
+            std::vector<uint8_t> p8(dev::kSearchP8Bytes, 0);
+            for (unsigned c1 = 0; c1 < 128; c1++)
+                for (unsigned c2 = 0; c2 < 128; c2++) p8[c1 * dev::kSearchP8Stride + c2] = (uint8_t)(2 * s2.pair_col[c1 * 128 + c2]);
+            auto lay = [&](const std::vector<uint32_t> &src) {
+                std::vector<uint16_t> T((size_t)s2.nrows * (rb / 2), 0);
+                for (uint32_t r = 0; r < s2.nrows; r++)
+                    for (uint32_t c = 0; c < s2.ncols; c++) {
+                        const uint32_t v = src[(size_t)r * s2.ncols + c];
+                        T[(size_t)r * (rb / 2) + c] = (uint16_t)((br + (v & 0xffffffu)) << 4 | (v >> 24));
+                    }
+                return T;
+            };
+            const std::vector<uint16_t> T = lay(s2.first), TA = lay(s2.all);
+            oP = put(p8.data(), p8.size());
+            oT = put(T.data(), T.size() * 2);
+            oTA = put(TA.data(), TA.size() * 2);
+        } else if (line_form) {
+            std::vector<uint16_t> p16((size_t)128 * dev::kSearchP16Stride, 0);
+            for (unsigned c1 = 0; c1 < 128; c1++)
+                for (unsigned c2 = 0; c2 < 128; c2++) p16[c1 * dev::kSearchP16Stride + c2] = (uint16_t)(4 * s2.pair_col[c1 * 128 + c2]);
+            auto lay = [&](const std::vector<uint32_t> &src) {
+                std::vector<uint32_t> T(src.size());
+                for (size_t i = 0; i < src.size(); i++) T[i] = (src[i] & 0xffffffu) * s2.ncols * 4u | (src[i] >> 24) << 28;
+                return T;
+            };
+            const std::vector<uint32_t> T = lay(s2.first), TA = lay(s2.all);
+            oP = put(p16.data(), p16.size() * 2);
+            oT = put(T.data(), T.size() * 4);
+            oTA = put(TA.data(), TA.size() * 4);
+        }
         if (line_form) {
-            const uint32_t row_bytes = search_line.ncols * 4;
-            std::vector<uint32_t> T(search_line.table.size());
-            for (size_t i = 0; i < T.size(); i++) {
-                const uint32_t v = search_line.table[i];
-                const uint32_t flags = (v & kSearchNewline) ? 1u : (v & kSearchHit) ? ((v & kSearchAnchored) ? 3u : 2u) : 0u;
-                T[i] = (v & 0xffffu) * row_bytes | flags << 16;
-            }
-            uint16_t c4[256];
-            for (int c = 0; c < 256; c++) c4[c] = (uint16_t)(search_fwd.cls[c] * 4);
-            c4['\n'] = (uint16_t)(K * 4);
             std::vector<uint16_t> rv(((size_t)NR * K + 1) & ~(size_t)1, 0);
             for (size_t i = 0; i < (size_t)NR * K; i++) { const uint16_t nx = search_rev.next[i]; rv[i] = (uint16_t)(nx | (search_rev.accepting[nx] ? 0x8000u : 0u)); }
-            // "restart" form for all matches: a hit leads back to the start row, the search goes on right behind the match
-            std::vector<uint32_t> TA(T);
-            for (size_t i = 0; i < TA.size(); i++) if ((TA[i] >> 16) & 2u) TA[i] = (TA[i] & 0xffff0000u) | (search_line.start * row_bytes);
-            oTL = put(T.data(), T.size() * 4);
-            oTA = put(TA.data(), TA.size() * 4);
-            oC4 = put(c4, sizeof c4);
             oRV = put(rv.data(), rv.size() * 2);
-            t.chunk.nrows = search_line.nrows; t.chunk.stride = search_line.ncols;
-            t.chunk.start_off = search_line.start * row_bytes; t.chunk.skip_off = search_line.skip * row_bytes;
-            t.chunk.nr = NR; t.chunk.ncls = K; t.chunk.start_r = search_rev.start;
         }
         HIP_TRY(hipMalloc(&t.blob, host.size() + 16));
         hipError_t e = hipMemcpy(t.blob, host.data(), host.size(), hipMemcpyHostToDevice);
@@ -435,12 +478,15 @@ struct rrx_regex {
         t.dev.next_f = reinterpret_cast<const uint16_t *>(base + oNF); t.dev.next_r = reinterpret_cast<const uint16_t *>(base + oNR);
         t.dev.acc_f = base + oAF; t.dev.acc_r = base + oAR;
         if (line_form) {
-            t.chunk.T = reinterpret_cast<const uint32_t *>(base + oTL);
-            t.chunk.T_all = reinterpret_cast<const uint32_t *>(base + oTA);
-            t.chunk.cls4 = reinterpret_cast<const uint16_t *>(base + oC4);
+            if (t.chunk.in_global) {
+                t.chunk.P16 = reinterpret_cast<const uint16_t *>(base + oP);
+                t.chunk.G2 = reinterpret_cast<const uint32_t *>(base + oT); t.chunk.G2_all = reinterpret_cast<const uint32_t *>(base + oTA);
+            } else {
+                t.chunk.P8 = base + oP;
+                t.chunk.T2 = reinterpret_cast<const uint16_t *>(base + oT); t.chunk.T2_all = reinterpret_cast<const uint16_t *>(base + oTA);
+            }
             t.chunk.rev = reinterpret_cast<const uint16_t *>(base + oRV);
             t.chunk.cls = base + oC;
-            if (dev::search_chunks_lds_bytes(t.chunk) > dev::kSearchChunkLdsBudget) t.chunk.nrows = 0;
         }
         auto ins = search_on_device.emplace(device, t);
         *out = &ins.first->second.dev;
@@ -828,6 +874,14 @@ size_t rrx_program_words(const rrx_regex *re, int kind, uint32_t *out, size_t ca
         w = {d.nrows, d.ncols, d.start, d.skip};
         for (int c = 0; c < 256; c++) w.push_back(c == '\n' ? d.ncols - 1 : re->search_fwd.cls[c]);
         w.insert(w.end(), d.table.begin(), d.table.end());
+    } else if (kind == RRX_PROGRAM_SEARCH_LINE2) {
+        std::lock_guard<std::mutex> lock(re->mu);
+        if (re->build_search() || !re->search_line2.nrows) return 0;
+        const SearchLine2Program &d = re->search_line2;
+        w = {d.nrows, d.ncols, d.start, d.skip, re->chunk_proto.nrows ? (re->chunk_proto.in_global ? 2u : 1u) : 0u};
+        for (uint16_t c : d.pair_col) w.push_back(c);
+        w.insert(w.end(), d.first.begin(), d.first.end());
+        w.insert(w.end(), d.all.begin(), d.all.end());
     } else if (kind == RRX_PROGRAM_DFA2_ORDER && re->has_dfa2) {
         std::lock_guard<std::mutex> lock(re->mu);
         if (re->t2_row_slot.size() != re->dfa2.nstates || re->t2_col_slot.size() != re->dfa2.ncols) return 0;
@@ -1149,7 +1203,7 @@ int rrx_search_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_star
     if (const dev::SearchChunkDevice *ct = re->search_chunk_tables(c->device)) {     // stripe-wise: one pass, coalesced results
         rc = chunk_index(c, stream);
         if (rc) return rc;
-        int e = dev::search_chunks(*ct, c->d_bytes, c->nbytes, c->d_chunk_base, c->nchunks, d_start, d_end, stream);
+        int e = dev::search_chunks(*ct, c->has_high, c->d_bytes, c->nbytes, c->d_chunk_base, c->nchunks, d_start, d_end, stream);
         if (e) return hip_fail((hipError_t)e, "search_chunks launch");
         return RRX_OK;
     }
@@ -1170,7 +1224,7 @@ int rrx_search_all_count(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_c
     if (const dev::SearchChunkDevice *ct = re->search_chunk_tables(c->device)) {     // stripe-wise
         rc = chunk_index(c, stream);
         if (rc) return rc;
-        int e = dev::search_chunks_count(*ct, c->d_bytes, c->nbytes, c->d_chunk_base, c->nchunks, d_count, stream);
+        int e = dev::search_chunks_count(*ct, c->has_high, c->d_bytes, c->nbytes, c->d_chunk_base, c->nchunks, d_count, stream);
         if (e) return hip_fail((hipError_t)e, "search_chunks_count launch");
         return RRX_OK;
     }
@@ -1191,7 +1245,7 @@ int rrx_search_all_fill(const rrx_regex *re, const rrx_corpus *c, const uint64_t
     if (const dev::SearchChunkDevice *ct = re->search_chunk_tables(c->device)) {     // stripe-wise
         rc = chunk_index(c, stream);
         if (rc) return rc;
-        int e = dev::search_chunks_fill(*ct, c->d_bytes, c->nbytes, c->d_chunk_base, c->nchunks, d_first, d_start, d_end, stream);
+        int e = dev::search_chunks_fill(*ct, c->has_high, c->d_bytes, c->nbytes, c->d_chunk_base, c->nchunks, d_first, d_start, d_end, stream);
         if (e) return hip_fail((hipError_t)e, "search_chunks_fill launch");
         return RRX_OK;
     }
@@ -1223,7 +1277,7 @@ int rrx_search_all(const rrx_regex *re, const rrx_corpus *c, uint64_t *d_first, 
             if (!c->d_all_scratch) HIP_TRY(hipMalloc(&c->d_all_scratch, sb));
         }
         HIP_TRY(hipMemsetAsync(c->d_all_scratch, 0, sb, st));
-        int e = dev::search_chunks_all(*ct, c->d_bytes, c->nbytes, c->d_chunk_base, c->nchunks, c->nlines, d_first, d_start, d_end, cap,
+        int e = dev::search_chunks_all(*ct, c->has_high, c->d_bytes, c->nbytes, c->d_chunk_base, c->nchunks, c->nlines, d_first, d_start, d_end, cap,
                                        c->d_all_scratch, stream);
         if (e) return hip_fail((hipError_t)e, "search_chunks_all launch");
         uint64_t tail[2] = {0, 0};                                 // total, {ticket, error flag}

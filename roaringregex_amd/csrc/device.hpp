@@ -205,15 +205,26 @@ struct SearchDevice {
     const uint8_t *acc_f = nullptr, *acc_r = nullptr;        // [n]
 };
 constexpr uint32_t kSearchLdsBudget = 64 * 1024;
-// Stripe-wise search (kernels_search.hip): the forward table in LINE MODE - one row per state plus the SKIP row (the line's
-// first match has been found: wait for '\n'), one column per byte class plus the '\n' column; entry = byte offset of the
-// next row (16 bits) | '\n' << 16 | hit << 17 (the byte completed the line's first match: next row = SKIP).
+// Stripe-wise search (kernels_search.hip).  The forward table is the LINE MODE product table (lower_search_line: one row per
+// reachable pair of states plus the SKIP row - the line's first match has been found: wait for '\n' -, one column per byte
+// class plus the '\n' column) in its STRIDE-2 form (lower_search_line2): one dependent lookup consumes two bytes and yields
+// the four event bits of the pair.  Two layouts:
+//   LDS form    (in_global = 0): P8[128][kSearchP8Stride] = 2 * pair column (a byte), T2 / T2_all[nrows][row_bytes / 2] with
+//               16-bit entries (base_row + next row) << 4 | events; the kernel puts P8 at LDS address 0 and the table at
+//               base_row * row_bytes, so that an entry's row field times row_bytes IS the row's LDS address;
+//   global form (in_global = 1): the table stays in HBM/L2 (any size up to 256 MiB), P16[128][kSearchP16Stride] = 4 * pair
+//               column in LDS, G2 / G2_all[nrows][ncols2] with 32-bit entries byte offset of the next row | events << 28.
+// events = (flags of the first byte) << 2 | flags of the second; flags: 1 '\n', 2 hit, 3 hit whose match starts at the restart point.
+constexpr uint32_t kSearchP8Stride = 132, kSearchP8Bytes = 128 * kSearchP8Stride;          // (33 dwords per row: odd)
+constexpr uint32_t kSearchP16Stride = 130, kSearchP16Bytes = 128 * kSearchP16Stride * 2;
 struct SearchChunkDevice {
-    uint32_t nrows = 0, stride = 0, start_off = 0, skip_off = 0;
+    uint32_t nrows = 0, ncols2 = 0, row_bytes = 0, base_row = 0, in_global = 0;
+    uint32_t start_row = 0, skip_row = 0;        // row indices (without base_row)
     uint32_t nr = 0, ncls = 0, start_r = 0;
-    const uint32_t *T = nullptr;                 // [nrows][stride]
-    const uint32_t *T_all = nullptr;             // the same with every hit leading back to the start row (all matches)
-    const uint16_t *cls4 = nullptr;              // [256] byte -> 4 * column
+    const uint8_t *P8 = nullptr;
+    const uint16_t *P16 = nullptr;
+    const uint16_t *T2 = nullptr, *T2_all = nullptr;
+    const uint32_t *G2 = nullptr, *G2_all = nullptr;
     const uint16_t *rev = nullptr;               // [nr][ncls] reverse table, bit 15 = leads to an accepting state
     const uint8_t *cls = nullptr;                // [256] byte -> class
 };
@@ -221,18 +232,19 @@ constexpr size_t kSearchChunkLdsBudget = 160 * 1024;     // one workgroup of 16 
 size_t search_chunk_bytes();                             // bytes of text per wave (the granularity of its newline index)
 size_t search_chunks_lds_bytes(const SearchChunkDevice &p);
 // chunk_base: per-chunk newline prefix in the stripe_base format (bit 63: the chunk begins at the start of a line)
-int search_chunks(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
+// clean: the text may hold bytes >= 0x80 (they cannot index the pair table: stepped as 0x00, which no pattern takes either)
+int search_chunks(const SearchChunkDevice &p, bool clean, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
                   uint32_t *match_start, uint32_t *match_end, void *stream);
 // all matches: count[line], then (with the caller's exclusive prefix `first`) the matches of line i at first[i], first[i] + 1, ...
-int search_chunks_count(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
+int search_chunks_count(const SearchChunkDevice &p, bool clean, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
                         uint32_t *count, void *stream);
-int search_chunks_fill(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
+int search_chunks_fill(const SearchChunkDevice &p, bool clean, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
                        const uint64_t *first, uint32_t *match_start, uint32_t *match_end, void *stream);
 // count and fill in one launch: first[nlines + 1] (CSR offsets of the lines' matches) and the matches themselves, slots
 // >= cap counted but not written; scratch = search_all_scratch_bytes(nchunks), zeroed before the launch, holds the
 // per-chunk status words, then the total (u64), then {ticket, error flag} (u32 each)
 size_t search_all_scratch_bytes(size_t nchunks);
-int search_chunks_all(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks, size_t nlines,
+int search_chunks_all(const SearchChunkDevice &p, bool clean, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks, size_t nlines,
                       uint64_t *first, uint32_t *match_start, uint32_t *match_end, size_t cap, void *scratch, void *stream);
 size_t search_lds_bytes(const SearchDevice &p);
 // line_off[i] = offset of the first byte of line i (built once per corpus from the stripe index); nlines + 1 entries are

@@ -3,10 +3,13 @@
 //
 // Geometry: a WAVE owns a contiguous chunk of 64 * S bytes, lane l its sub-stripe [l*S, (l+1)*S) (S = 256: two cache
 // lines per lane, one after the other in registers).  A line belongs to the lane its first byte lies in.  Per lane:
-//   1. forward pass over its S bytes with the line-mode forward table in LDS ("any bytes, then the pattern"; rows carry
-//      two flags: the byte was '\n' / the byte completed the first match of its line, after which the row is SKIP until
-//      the next '\n'): 2 LDS gathers and 4 VALU per byte, no branch - the flags are shifted into event words, 2 bits per
-//      byte;
+//   1. forward pass over its S bytes with the line-mode forward table ("any bytes, then the pattern"; an entry carries two
+//      flags per byte: the byte was '\n' / the byte completed the first match of its line, after which the row is SKIP
+//      until the next '\n') in its STRIDE-2 form: the pair's column comes from a table indexed by the two bytes (its read does
+//      not wait for the state), then one dependent lookup consumes both bytes and yields their four event bits - 2 LDS
+//      gathers per PAIR (round 3: per byte; the LDS pipe is what bounds the pass), no branch; the flags are shifted into
+//      event words, 2 bits per byte.  FORM kLdsForm: the table in LDS with 16-bit entries; kGlobalForm: the table in
+//      HBM/L2 (product tables beyond the LDS: any size), only the pair table in LDS;
 //   2. a wave prefix sum of the lanes' '\n' counts numbers the lines (the chunk's first line number comes from a per-chunk
 //      newline index, as the match kernel's stripes have);
 //   3. the hit events are visited in byte order (first match: the hits only - a hit's line number and line start are a
@@ -41,14 +44,13 @@ constexpr uint32_t kDirect = 0xfffffffeu;       // staged entry: the result did 
 typedef const __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
 typedef const __attribute__((address_space(3))) uint16_t *lds_u16_ptr;
 
+enum { kLdsForm = 0, kGlobalForm = 1 };
 struct SearchLds {
-    const uint8_t *T;                           // forward line table, byte-addressed
-    const uint16_t *cls4;                       // [256] byte -> 4 * column of the forward table ('\n' -> its own column)
     // reverse table, as the kernel lays it out in LDS: entry = byte offset of the next state's row | 1 if that state is
     // accepting (rows are 2 * K bytes: even); row 0 = dead (every entry leads back to it); cls2 = byte -> 2 * class
     uint32_t rev_base, cls2_base;               // LDS addresses
     uint32_t start_row;                         // row offset of the reverse start state
-    uint32_t start_off, skip_off;
+    uint32_t start_e, skip_e;                   // forward table: the entry values "at the start row" / "at the SKIP row"
 };
 typedef const __attribute__((address_space(3))) uint8_t *lds_u8_ptr;
 
@@ -133,29 +135,40 @@ __device__ __forceinline__ uint64_t chunk_lookback(uint64_t *status, uint32_t *t
 // MODE kCount: match_start[line] = number of matches of the line (match_end unused).
 // MODE kFill : match_start/match_end[first[line] + k] = k-th match of the line.
 // MODE kAll  : the same, with first[] produced here as well (all.first_out) and the slots bounded by all.cap.
-template <int MODE>
-__global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void search_chunks_kernel(SearchChunkDevice prog, const uint8_t *__restrict__ bytes, size_t nbytes,
+template <int MODE, int FORM>
+__global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void search_chunks_kernel(SearchChunkDevice prog, uint32_t clean, const uint8_t *__restrict__ bytes, size_t nbytes,
                                                                           const uint64_t *__restrict__ chunk_base, size_t nchunks,
                                                                           const uint64_t *__restrict__ first,
                                                                           uint32_t *__restrict__ match_start, uint32_t *__restrict__ match_end,
                                                                           uint32_t kStageLines, SearchAllArgs all) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     // ---- tables into LDS, once per workgroup: its waves then take chunk after chunk (a chunk is only 16 KiB of text, the
-    // tables can be several times that).  The byte -> column table comes first, at LDS address 0, so that 2 * byte IS its address
-    // (checked below); the forward table's entries get the table's LDS address added: entry.word[0] + column = address.
-    const uint32_t t_words = prog.nrows * prog.stride, rev_words = (prog.nr * prog.ncls + 1) / 2;
-    uint32_t *C4 = reinterpret_cast<uint32_t *>(smem);            // 128 words
-    uint32_t *T = C4 + 128;
-    uint32_t *R = T + t_words;
+    // tables can be several times that).  The pair table comes first, at LDS address 0, so that the pair's index IS its
+    // address (the dynamic LDS starts at address 0: no static LDS in this kernel, the launcher checks it on the host); the
+    // forward table (LDS form) starts at a multiple of its row size: an entry's row field times the row size is an address.
+    const uint32_t rev_words = (prog.nr * prog.ncls + 1) / 2;
+    uint32_t tab_end;                                             // bytes of LDS the forward tables take
+    const uint32_t *G = nullptr;                                  // global form: the table in HBM/L2
+    if constexpr (FORM == kLdsForm) {
+        uint32_t *P = reinterpret_cast<uint32_t *>(smem);
+        for (uint32_t i = threadIdx.x; i < kSearchP8Bytes / 4; i += blockDim.x) P[i] = reinterpret_cast<const uint32_t *>(prog.P8)[i];
+        const uint32_t t_base = prog.base_row * prog.row_bytes, t_words = prog.nrows * (prog.row_bytes / 4);
+        uint32_t *T = reinterpret_cast<uint32_t *>(smem + t_base);
+        const uint32_t *Tsrc = reinterpret_cast<const uint32_t *>(MODE == kFirst ? prog.T2 : prog.T2_all);
+        for (uint32_t i = threadIdx.x; i < t_words; i += blockDim.x) T[i] = Tsrc[i];
+        tab_end = t_base + 4u * t_words;
+    } else {
+        uint32_t *P = reinterpret_cast<uint32_t *>(smem);
+        for (uint32_t i = threadIdx.x; i < kSearchP16Bytes / 4; i += blockDim.x) P[i] = reinterpret_cast<const uint32_t *>(prog.P16)[i];
+        tab_end = kSearchP16Bytes;
+        G = MODE == kFirst ? prog.G2 : prog.G2_all;
+    }
+    uint32_t *R = reinterpret_cast<uint32_t *>(smem + tab_end);
     uint32_t *C = R + rev_words;                                  // 64 words
     uint32_t *pool_all = C + 64;                                  // [wave][kPoolWords]: the waves' walk jobs
     uint32_t *stage = pool_all + kSearchWaves * kPoolWords;       // [wave][kArrays][kStageLines]
     constexpr uint32_t kArrays = (MODE == kFill || MODE == kAll) ? 2 : 1;     // results packed start | end << 16 (kCount: the count); kFill / kAll: + slot bases
     constexpr uint32_t kStageInit = MODE == kCount ? 0u : kNone;  // a line without a match: "none" / zero matches
-    const uint32_t t_base = 512u;                                 // LDS address of T: the dynamic LDS starts at address 0 (no static
-                                                                  // LDS in this kernel; the launcher checks it on the host)
-    const uint32_t *Tsrc = MODE == kFirst ? prog.T : prog.T_all;
-    for (uint32_t i = threadIdx.x; i < t_words; i += blockDim.x) T[i] = Tsrc[i] + t_base;
     // the reverse table changes form on the way in: next state | accepting << 15  ->  row offset | accepting (see SearchLds);
     // the byte -> class map is doubled (classes are < 128)
     const uint32_t rev_row = 2u * prog.ncls;
@@ -164,14 +177,48 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
         const uint32_t a = (w & 0x7fffu) * rev_row | ((w >> 15) & 1u), b = ((w >> 16) & 0x7fffu) * rev_row | (w >> 31);
         R[i] = a | b << 16;
     }
-    for (uint32_t i = threadIdx.x; i < 128; i += blockDim.x) C4[i] = reinterpret_cast<const uint32_t *>(prog.cls4)[i];
     for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x) C[i] = (reinterpret_cast<const uint32_t *>(prog.cls)[i] << 1) & 0xfefefefeu;
     for (uint32_t i = threadIdx.x; i < kSearchWaves * kArrays * kStageLines; i += blockDim.x) stage[i] = kStageInit;
     __syncthreads();
     SearchLds t;
-    t.T = smem; t.cls4 = reinterpret_cast<const uint16_t *>(C4);
-    t.rev_base = t_base + 4u * t_words; t.cls2_base = t.rev_base + 4u * rev_words; t.start_row = prog.start_r * rev_row;
-    t.start_off = prog.start_off + t_base; t.skip_off = prog.skip_off + t_base;
+    t.rev_base = tab_end; t.cls2_base = t.rev_base + 4u * rev_words; t.start_row = prog.start_r * rev_row;
+    if constexpr (FORM == kLdsForm) { t.start_e = (prog.base_row + prog.start_row) << 4; t.skip_e = (prog.base_row + prog.skip_row) << 4; }
+    else { t.start_e = prog.start_row * prog.ncols2 * 4u; t.skip_e = prog.skip_row * prog.ncols2 * 4u; }
+    const uint32_t row_bytes = prog.row_bytes;
+    // ---- the forward step.  pair_index: where the column of each of the two byte pairs of a text word stands in the pair table
+    // (= its LDS address); pair_column: that column; step_pair: the dependent lookup, the pair's four event bits shifted into acc.
+    //     LDS form    i = c1 * 132 + c2;  col = P8[i] (2 * column);   e = T2[(e >> 4) * row_bytes + col] (u16);  acc = acc << 4 | (e & 15)
+    //     global form i = 2 c1 * 130 + 2 c2;  col = P16[i] (4 * column);  e = G2[(e & 0x0fffffff) + col];      acc = {acc, e} >> 28
+    // (asm volatile keeps the lookups of a few pairs ahead of their steps and no more: left to itself the scheduler hoists every
+    // column lookup of a round and spills their results.)  Bytes >= 0x80 cannot index the pair table: `clean` (a corpus that
+    // holds any) rewrites them to 0x00 - no pattern takes either - under a wave-uniform branch per 16 bytes.
+    auto clean_word = [](uint32_t w) -> uint32_t { const uint32_t hi = (w & 0x80808080u) >> 7; return w & ~(hi * 0xffu); };
+    auto pair_index = [&](uint32_t w, uint32_t &ia, uint32_t &ib) {
+        const uint32_t x = FORM == kGlobalForm ? w << 1 : w;
+        const uint32_t stride = FORM == kGlobalForm ? kSearchP16Stride : kSearchP8Stride;
+        uint32_t ta, tb;
+        // (the two multiplies first: an SDWA read of a register the instruction before wrote costs a wait state)
+        asm volatile("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(ta) : "v"(x), "v"(stride));
+        asm volatile("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(tb) : "v"(x), "v"(stride));
+        asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(ia) : "v"(ta), "v"(x));
+        asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(ib) : "v"(tb), "v"(x));
+    };
+    auto pair_column = [&](uint32_t i) -> uint32_t {
+        if constexpr (FORM == kLdsForm) return *reinterpret_cast<lds_u8_ptr>(i);
+        else return *reinterpret_cast<lds_u16_ptr>(i);
+    };
+    auto step_pair = [&](uint32_t &e, uint32_t col, uint32_t &acc) {
+        uint32_t a_;
+        if constexpr (FORM == kLdsForm) {
+            asm volatile("v_lshrrev_b32 %0, 4, %1\n\tv_mad_u32_u24 %0, %0, %2, %3" : "=&v"(a_) : "v"(e), "s"(row_bytes), "v"(col));
+            e = *reinterpret_cast<lds_u16_ptr>(a_);
+            asm volatile("v_and_b32 %0, 15, %2\n\tv_lshl_or_b32 %1, %1, 4, %0" : "=&v"(a_), "+v"(acc) : "v"(e));
+        } else {
+            asm volatile("v_and_b32 %0, 0x0fffffff, %1\n\tv_add_u32 %0, %0, %2" : "=&v"(a_) : "v"(e), "v"(col));
+            e = *reinterpret_cast<const uint32_t *>(reinterpret_cast<const uint8_t *>(G) + a_);
+            asm volatile("v_alignbit_b32 %0, %0, %1, 28" : "+v"(acc) : "v"(e));
+        }
+    };
 
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint32_t *st_s = stage + (size_t)wave * kArrays * kStageLines;
@@ -195,16 +242,11 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     const size_t my_end = my + kSearchS < cend ? my + kSearchS : (my < cend ? cend : my);
     const uint32_t vlen = (uint32_t)(my_end - my);                // my bytes: kSearchS except at the end of the corpus
 
-    auto step = [&](uint32_t &e, uint32_t c) -> uint32_t {        // -> flags: bit 0 = '\n', bit 1 = hit
-        e = *reinterpret_cast<lds_u32_ptr>((e & 0xffffu) + t.cls4[c]);
-        return (e >> 16) & 3u;
-    };
-
     // ---- 1. forward pass over my bytes.  Lanes start in SKIP unless a line starts at their first byte.
     const uint32_t last_byte = vlen ? bytes[my_end - 1] : 0u;
     uint32_t prev_last = __shfl_up(last_byte, 1, 64);
     const bool fresh = vlen && (lane == 0 ? chunk_fresh : prev_last == '\n');
-    uint32_t e = fresh ? t.start_off : t.skip_off;
+    uint32_t e = fresh ? t.start_e : t.skip_e;
     constexpr int kEv = kSearchS / 16;
     uint32_t ev[kEv];                                             // 2 bits per byte, the first byte of a word highest
     {
@@ -229,33 +271,25 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
             });
         }
         int slot = 8 * kR;
-        text.for_each_slot([&](const uint4 &v) {
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        text.for_each_slot([&](const uint4 &v0) {
+            uint4 v = v0;
+            if (clean && __builtin_amdgcn_ballot_w64(((v.x | v.y | v.z | v.w) & 0x80808080u) != 0)) {
+                v.x = clean_word(v.x); v.y = clean_word(v.y); v.z = clean_word(v.z); v.w = clean_word(v.w);
+            }
             uint32_t acc = 0;
-            // per byte: 2 * byte (SDWA) -> column offset (ds_read_u16) -> entry.word[0] + column (SDWA) -> entry
-            // (ds_read_b32) -> the two event bits shifted in: 4 VALU + 2 LDS.  The four column lookups of a text word do
-            // not depend on the state: they are issued together, ahead of the four dependent steps.  (asm volatile:
-            // left to itself the scheduler hoists all 128 column lookups of the round and spills their results.)
-#define RRX_SEARCH_COL(W, SEL, A, C)                                                                                              \
-            asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL : "=v"(A) : "v"(1u), "v"(W)); \
-            C = *reinterpret_cast<lds_u16_ptr>(A);
-#define RRX_SEARCH_STEP(C)                                                                                                        \
-            {                                                                                                                     \
-                uint32_t a_;                                                                                                      \
-                asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(a_) : "v"(e), "v"(C)); \
-                e = *reinterpret_cast<lds_u32_ptr>(a_);                                                                          \
-                acc <<= 2;                                                                                                        \
-                asm volatile("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(acc) : "v"(e), "v"(acc)); \
+            // the columns of four pairs (two text words) are looked up ahead of their four dependent steps
+            {
+                uint32_t i0, i1, i2, i3;
+                pair_index(v.x, i0, i1); pair_index(v.y, i2, i3);
+                const uint32_t c0 = pair_column(i0), c1 = pair_column(i1), c2 = pair_column(i2), c3 = pair_column(i3);
+                step_pair(e, c0, acc); step_pair(e, c1, acc); step_pair(e, c2, acc); step_pair(e, c3, acc);
             }
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                uint32_t a0, a1, a2, a3, c0, c1, c2, c3;
-                RRX_SEARCH_COL(w[q], "BYTE_0", a0, c0) RRX_SEARCH_COL(w[q], "BYTE_1", a1, c1)
-                RRX_SEARCH_COL(w[q], "BYTE_2", a2, c2) RRX_SEARCH_COL(w[q], "BYTE_3", a3, c3)
-                RRX_SEARCH_STEP(c0) RRX_SEARCH_STEP(c1) RRX_SEARCH_STEP(c2) RRX_SEARCH_STEP(c3)
+            {
+                uint32_t i0, i1, i2, i3;
+                pair_index(v.z, i0, i1); pair_index(v.w, i2, i3);
+                const uint32_t c0 = pair_column(i0), c1 = pair_column(i1), c2 = pair_column(i2), c3 = pair_column(i3);
+                step_pair(e, c0, acc); step_pair(e, c1, acc); step_pair(e, c2, acc); step_pair(e, c3, acc);
             }
-#undef RRX_SEARCH_STEP
-#undef RRX_SEARCH_COL
             // (slot is a compile-time constant after inlining: the lambda is expanded once per slot)
             ev[slot++] = acc;
         });
@@ -453,6 +487,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
         next_slot = reserve(n) + off;
     };
     constexpr bool kWalks = !COUNTING && MODE != kCount;          // this pass queues jobs
+    constexpr int kFollowTurnWords = (kWalks && MODE != kFirst) ? 1 : 4;      // text words per turn of the follow loop (see there)
     // ---- 4a. my events, word by word (a static loop over the event words, a dynamic one over the events of a word: the
     // version with one loop body that rotated the words through ev[0] paid 7 extra turns per lane and a longer body)
     if constexpr (MODE == kAll && COUNTING) {
@@ -572,52 +607,78 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
             phase = 2;
         }
     }
-    size_t fbyte = my_end;                                        // follow position (word by word while whole 16-byte blocks lie in the data)
+    size_t fbyte = my_end;                                        // follow position: a multiple of 16 (my_end is a multiple of kSearchS, or the end of the data)
     uint4 cur = make_uint4(0, 0, 0, 0), nxt = cur;
     if (phase == 1 && fbyte + 16 <= nbytes) cur = *reinterpret_cast<const uint4 *>(bytes + fbyte);
     {
-        // ---- 4b. the rest of my last line: sixteen bytes per load, the next sixteen requested before these are stepped
-        // (the loop is a chain of memory round trips otherwise), stepped like the forward pass, a text word per turn
-        auto follow_step = [&](uint32_t &acc, uint32_t &wrel) {   // -> the events of the word stepped (2 bits per byte, byte 0 in bits 7..6)
+        // ---- 4b. the rest of my last line: SIXTEEN bytes per turn (round 3: four - the loop runs until the wave's longest line
+        // is done, and what a turn costs beside its steps was paid per four bytes: 0.98 of 3.69 ms on the URL config,
+        // profiles/r04_search_ablation.txt), the next sixteen requested before these are stepped (the loop is a chain of memory
+        // round trips otherwise), stepped like the forward pass
+        // kTurnWords text words per turn: four, or one in the passes that place every match (kFill, the second pass of kAll:
+        // where every byte is a match - all matches of a{1,300} - the sixteen-byte turn measured 38 % SLOWER, 22.5 against 16.3 ms
+        // per GiB in the fill pass; tools/probe/search_ablate/follow_ab.sh)
+        constexpr int kTurnWords = kFollowTurnWords;
+        auto follow_step = [&](uint32_t &acc, uint32_t &wrel) {   // -> the events of the bytes stepped (2 bits per byte, the first byte in bits 31..30)
             const size_t fpos = fbyte & ~(size_t)15;
             if (fpos + 16 <= nbytes) {
-                const uint32_t fq = (uint32_t)(fbyte & 15) >> 2;  // text word of `cur` to step
+                const uint32_t fq = (uint32_t)(fbyte & 15) >> 2;  // text word of `cur` to step (four words per turn: always 0)
                 if (fq == 0 && fpos + 32 <= nbytes) nxt = *reinterpret_cast<const uint4 *>(bytes + fpos + 16);
-                const uint32_t w = fq == 0 ? cur.x : fq == 1 ? cur.y : fq == 2 ? cur.z : cur.w;
-                uint32_t a0, a1, a2, a3, c0, c1, c2, c3;
-#define RRX_SEARCH_COL(W, SEL, A, C)                                                                                              \
-                asm volatile("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:" SEL : "=v"(A) : "v"(1u), "v"(W)); \
-                C = *reinterpret_cast<lds_u16_ptr>(A);
-#define RRX_SEARCH_STEP(C)                                                                                                        \
-                {                                                                                                                 \
-                    uint32_t a_;                                                                                                  \
-                    asm volatile("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(a_) : "v"(e), "v"(C)); \
-                    e = *reinterpret_cast<lds_u32_ptr>(a_);                                                                      \
-                    acc <<= 2;                                                                                                    \
-                    asm volatile("v_or_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(acc) : "v"(e), "v"(acc)); \
+                if constexpr (kTurnWords == 4) {
+                    uint4 v = cur;
+                    if (clean) { v.x = clean_word(v.x); v.y = clean_word(v.y); v.z = clean_word(v.z); v.w = clean_word(v.w); }
+                    {
+                        uint32_t i0, i1, i2, i3;
+                        pair_index(v.x, i0, i1); pair_index(v.y, i2, i3);
+                        const uint32_t c0 = pair_column(i0), c1 = pair_column(i1), c2 = pair_column(i2), c3 = pair_column(i3);
+                        step_pair(e, c0, acc); step_pair(e, c1, acc); step_pair(e, c2, acc); step_pair(e, c3, acc);
+                    }
+                    {
+                        uint32_t i0, i1, i2, i3;
+                        pair_index(v.z, i0, i1); pair_index(v.w, i2, i3);
+                        const uint32_t c0 = pair_column(i0), c1 = pair_column(i1), c2 = pair_column(i2), c3 = pair_column(i3);
+                        step_pair(e, c0, acc); step_pair(e, c1, acc); step_pair(e, c2, acc); step_pair(e, c3, acc);
+                    }
+                } else {
+                    uint32_t w = fq == 0 ? cur.x : fq == 1 ? cur.y : fq == 2 ? cur.z : cur.w;
+                    if (clean) w = clean_word(w);
+                    uint32_t ia, ib;
+                    pair_index(w, ia, ib);
+                    const uint32_t ca = pair_column(ia), cb = pair_column(ib);
+                    step_pair(e, ca, acc); step_pair(e, cb, acc);
+                    acc <<= 24;
                 }
-                RRX_SEARCH_COL(w, "BYTE_0", a0, c0) RRX_SEARCH_COL(w, "BYTE_1", a1, c1) RRX_SEARCH_COL(w, "BYTE_2", a2, c2) RRX_SEARCH_COL(w, "BYTE_3", a3, c3)
-                RRX_SEARCH_STEP(c0) RRX_SEARCH_STEP(c1) RRX_SEARCH_STEP(c2) RRX_SEARCH_STEP(c3)
-#undef RRX_SEARCH_STEP
-#undef RRX_SEARCH_COL
                 wrel = (uint32_t)(fbyte - cstart);
-                fbyte += 4;
+                fbyte += 4 * kTurnWords;
                 if ((fbyte & 15) == 0) cur = nxt;
-            } else {                                              // the last bytes of the corpus, one by one
+            } else {                                              // the last bytes of the corpus, pair by pair
                 next_slot = kPool;                                // (no slots reserved here: these few hits walk alone)
-                for (; fbyte < nbytes && phase == 1; fbyte++) {
-                    const uint32_t f = step(e, bytes[fbyte]);
-                    if (f == 1u) phase = 2;
-                    else if (f) { follow_hit((uint32_t)(fbyte - cstart), f); if (MODE == kFirst) phase = 2; }
+                for (; fbyte < nbytes && phase == 1; fbyte += 2) {  // (fbyte is even: pairs stay aligned; a last odd byte is paired with 0x00)
+                    uint32_t c1 = bytes[fbyte], c2 = fbyte + 1 < nbytes ? bytes[fbyte + 1] : 0u;
+                    if (c1 & 0x80u) c1 = 0;
+                    if (c2 & 0x80u) c2 = 0;
+                    uint32_t pa = 0;
+                    {
+                        uint32_t ia, ib;
+                        pair_index(c1 | c2 << 8, ia, ib);
+                        step_pair(e, pair_column(ia), pa);
+                    }
+                    const uint32_t f1 = (pa >> 2) & 3u, f2 = pa & 3u;
+                    if (f1 == 1u) phase = 2;
+                    else if (f1) { follow_hit((uint32_t)(fbyte - cstart), f1); if (MODE == kFirst) phase = 2; }
+                    if (phase == 1 && fbyte + 1 < nbytes) {
+                        if (f2 == 1u) phase = 2;
+                        else if (f2) { follow_hit((uint32_t)(fbyte + 1 - cstart), f2); if (MODE == kFirst) phase = 2; }
+                    }
                 }
                 if (fbyte >= nbytes) phase = 2;                   // the end of the data ends the line
             }
         };
-        auto follow_events = [&](uint32_t acc, uint32_t wrel) {
+        auto follow_events = [&](uint32_t acc, uint32_t wrel) {   // the events of a turn (or of a part of it: fields masked out are zero) in byte order
             while (acc && phase == 1) {
-                const int z = (__clz((int)acc) - 24) >> 1;
-                const uint32_t f = (acc >> (6 - 2 * z)) & 3u;
-                acc &= ~(3u << (6 - 2 * z));
+                const int z = __clz((int)acc) >> 1;
+                const uint32_t f = (acc >> (30 - 2 * z)) & 3u;
+                acc &= ~(3u << (30 - 2 * z));
                 if (f == 1u) phase = 2;                           // the line's '\n': done (what lies behind it is not mine)
                 else { follow_hit(wrel + (uint32_t)z, f); if (MODE == kFirst) phase = 2; }
             }
@@ -629,10 +690,11 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
                 if (phase == 1) follow_step(acc, wrel);
                 if (__ballot(acc != 0)) {                         // (most turns meet neither a '\n' nor a hit)
                     // only the events up to the one that ends my following count: the line's '\n' (kFirst: or the first hit)
-                    uint32_t stop = acc & ~(acc >> 1) & 0x55u;
-                    if constexpr (MODE == kFirst) stop |= (acc >> 1) & 0x55u;
+                    uint32_t stop = acc & ~(acc >> 1) & 0x55555555u;
+                    if constexpr (MODE == kFirst) stop |= (acc >> 1) & 0x55555555u;
                     if (stop) acc &= ~((1u << (31 - __clz((int)stop))) - 1u);
-                    reserve_for((uint32_t)__popc((acc >> 1) & ~acc & 0x55u));       // my hits whose start is not known (fields equal to 2)
+                    // (first match: at most one hit is left; one word per turn: at most four)
+                    reserve_for((uint32_t)__popc((acc >> 1) & ~acc & 0x55555555u));           // my hits whose start is not known (fields equal to 2)
                     follow_events(acc, wrel);
                 }
             }
@@ -706,13 +768,19 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
 }  // namespace
 
 size_t search_chunk_bytes() { return kSearchChunk; }
-static size_t search_table_bytes(const SearchChunkDevice &p) { return ((size_t)p.nrows * p.stride + (p.nr * p.ncls + 1) / 2 + 128 + 64 + (size_t)kSearchWaves * kPoolWords) * 4; }   // tables + the waves' job pools
+// forward tables (LDS form: pair table, gap, table; global form: pair table) + reverse table + class map + the waves' job pools
+static size_t search_table_bytes(const SearchChunkDevice &p) {
+    const size_t fwd = p.in_global ? (size_t)kSearchP16Bytes : ((size_t)p.base_row + p.nrows) * p.row_bytes;
+    return fwd + ((size_t)(p.nr * p.ncls + 1) / 2 + 64 + (size_t)kSearchWaves * kPoolWords) * 4;
+}
 // staged entries per wave: what the tables and the job pools leave of the budget (the whole LDS of a CU), a multiple of 64, 128 at least
 // (one array of packed results or counts; the fill pass also keeps the lines' slot bases)
 static uint32_t search_stage_lines(const SearchChunkDevice &p, int mode) {
     const size_t tb = search_table_bytes(p), per = (size_t)kSearchWaves * 4 * ((mode == kFill || mode == kAll) ? 2 : 1);
     if (tb + per * 128 > kSearchChunkLdsBudget) return 0;
     if ((size_t)p.nr * p.ncls * 2 > 65534 || p.ncls > 128) return 0;      // reverse rows are addressed by 16-bit byte offsets, classes doubled in a byte
+    if (!p.in_global && (p.base_row + p.nrows > 4096 || p.ncols2 > 127 || (p.row_bytes & 3) || p.base_row * p.row_bytes < kSearchP8Bytes)) return 0;
+    if (p.in_global && ((size_t)p.nrows * p.ncols2 * 4 >= ((size_t)1 << 28) || p.ncols2 > 16383)) return 0;
     size_t n = (kSearchChunkLdsBudget - tb) / per;
     n = n / 64 * 64;
     return (uint32_t)(n > kMaxStageLines ? kMaxStageLines : n);
@@ -721,15 +789,15 @@ size_t search_chunks_lds_bytes(const SearchChunkDevice &p) {          // of the 
     const uint32_t n = search_stage_lines(p, kFill);
     return n ? search_table_bytes(p) + (size_t)kSearchWaves * 8 * n : (size_t)kSearchChunkLdsBudget + 1;
 }
-template <int MODE>
-static int launch_search_chunks(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
-                                const uint64_t *first, uint32_t *out0, uint32_t *out1, void *stream, SearchAllArgs all = SearchAllArgs()) {
+template <int MODE, int FORM>
+static int launch_search_chunks_form(const SearchChunkDevice &p, bool clean, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
+                                     const uint64_t *first, uint32_t *out0, uint32_t *out1, void *stream, SearchAllArgs all) {
     if (!nchunks) return 0;
     const uint32_t lines = search_stage_lines(p, MODE);
     if (!lines) return (int)hipErrorInvalidValue;
     const size_t lds = search_table_bytes(p) + (size_t)kSearchWaves * 4 * ((MODE == kFill || MODE == kAll) ? 2 : 1) * lines;
     static LdsAttr attr;
-    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(search_chunks_kernel<MODE>), lds, /*at_zero=*/true);
+    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(search_chunks_kernel<MODE, FORM>), lds, /*at_zero=*/true);
     if (e != hipSuccess) return (int)e;
     // persistent workgroups: the tables are loaded once per workgroup, its waves take chunk after chunk.  One workgroup per
     // CU and no more: a workgroup holds the CU's whole LDS, so a second generation could only start on a CU when all sixteen
@@ -744,26 +812,32 @@ static int launch_search_chunks(const SearchChunkDevice &p, const uint8_t *bytes
     }
     size_t blocks = (nchunks + kSearchWaves - 1) / kSearchWaves;
     if (blocks > (size_t)cus) blocks = (size_t)cus;
-    hipLaunchKernelGGL(search_chunks_kernel<MODE>, dim3((unsigned)blocks), dim3(kSearchWaves * 64), lds, (hipStream_t)stream, p, bytes, nbytes, chunk_base,
-                       nchunks, first, out0, out1, lines, all);
+    hipLaunchKernelGGL((search_chunks_kernel<MODE, FORM>), dim3((unsigned)blocks), dim3(kSearchWaves * 64), lds, (hipStream_t)stream, p, clean ? 1u : 0u, bytes,
+                       nbytes, chunk_base, nchunks, first, out0, out1, lines, all);
     return (int)hipGetLastError();
 }
-int search_chunks(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
+template <int MODE>
+static int launch_search_chunks(const SearchChunkDevice &p, bool clean, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
+                                const uint64_t *first, uint32_t *out0, uint32_t *out1, void *stream, SearchAllArgs all = SearchAllArgs()) {
+    return p.in_global ? launch_search_chunks_form<MODE, kGlobalForm>(p, clean, bytes, nbytes, chunk_base, nchunks, first, out0, out1, stream, all)
+                       : launch_search_chunks_form<MODE, kLdsForm>(p, clean, bytes, nbytes, chunk_base, nchunks, first, out0, out1, stream, all);
+}
+int search_chunks(const SearchChunkDevice &p, bool clean, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
                   uint32_t *match_start, uint32_t *match_end, void *stream) {
-    return launch_search_chunks<kFirst>(p, bytes, nbytes, chunk_base, nchunks, nullptr, match_start, match_end, stream);
+    return launch_search_chunks<kFirst>(p, clean, bytes, nbytes, chunk_base, nchunks, nullptr, match_start, match_end, stream);
 }
-int search_chunks_count(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
+int search_chunks_count(const SearchChunkDevice &p, bool clean, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
                         uint32_t *count, void *stream) {
-    return launch_search_chunks<kCount>(p, bytes, nbytes, chunk_base, nchunks, nullptr, count, nullptr, stream);
+    return launch_search_chunks<kCount>(p, clean, bytes, nbytes, chunk_base, nchunks, nullptr, count, nullptr, stream);
 }
-int search_chunks_fill(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
+int search_chunks_fill(const SearchChunkDevice &p, bool clean, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
                        const uint64_t *first, uint32_t *match_start, uint32_t *match_end, void *stream) {
-    return launch_search_chunks<kFill>(p, bytes, nbytes, chunk_base, nchunks, first, match_start, match_end, stream);
+    return launch_search_chunks<kFill>(p, clean, bytes, nbytes, chunk_base, nchunks, first, match_start, match_end, stream);
 }
 
 // scratch of search_chunks_all: status u64[nchunks] | total u64 | ticket u32[2]; zeroed by the caller before every launch
 size_t search_all_scratch_bytes(size_t nchunks) { return nchunks * sizeof(uint64_t) + 16; }
-int search_chunks_all(const SearchChunkDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks, size_t nlines,
+int search_chunks_all(const SearchChunkDevice &p, bool clean, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks, size_t nlines,
                       uint64_t *first, uint32_t *match_start, uint32_t *match_end, size_t cap, void *scratch, void *stream) {
     SearchAllArgs a;
     a.first_out = first;
@@ -772,7 +846,7 @@ int search_chunks_all(const SearchChunkDevice &p, const uint8_t *bytes, size_t n
     a.ticket = reinterpret_cast<uint32_t *>(a.total + 1);
     a.cap = cap;
     a.nlines = nlines;
-    return launch_search_chunks<kAll>(p, bytes, nbytes, chunk_base, nchunks, nullptr, match_start, match_end, stream, a);
+    return launch_search_chunks<kAll>(p, clean, bytes, nbytes, chunk_base, nchunks, nullptr, match_start, match_end, stream, a);
 }
 
 }  // namespace dev

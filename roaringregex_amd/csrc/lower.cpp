@@ -1171,6 +1171,61 @@ bool lower_search_line(const DfaProgram &fwd, const DfaProgram &anch, uint32_t m
     return true;
 }
 
+// Stride-2 form of the line-mode search table: both forms (first match: a hit leads to SKIP; all matches: back to the start
+// row) composed with themselves, the pair columns shared between them so that one pair table serves both.
+bool lower_search_line2(const SearchLineProgram &s, const uint32_t *column, uint32_t max_cols, SearchLine2Program &o) {
+    o = SearchLine2Program();
+    const uint32_t R = s.nrows, C = s.ncols;
+    if (!R || (uint64_t)C * C * R > ((uint64_t)1 << 28)) return false;              // (host work: two passes over C * C * R entries)
+    o.nrows = R; o.start = s.start; o.skip = s.skip;
+    auto flags_of = [](uint32_t v) -> uint32_t { return (v & kSearchNewline) ? 1u : (v & kSearchHit) ? ((v & kSearchAnchored) ? 3u : 2u) : 0u; };
+    // one step of either form: -> next row, flags
+    auto step = [&](uint32_t row, uint32_t sym, bool restart, uint32_t &f) -> uint32_t {
+        const uint32_t v = s.table[(size_t)row * C + sym];
+        f = flags_of(v);
+        return (restart && (f & 2u)) ? s.start : (v & 0xffffu);
+    };
+    std::unordered_map<uint64_t, std::vector<uint32_t>> by_hash;                    // hash of a column -> columns with that hash
+    std::vector<std::vector<uint32_t>> col_data;                                    // [column][2 * R]: the first form, then the restart form
+    std::vector<uint32_t> sym_pair_col((size_t)C * C);
+    std::vector<uint32_t> col(2 * (size_t)R);
+    for (uint32_t a = 0; a < C; a++)
+        for (uint32_t b = 0; b < C; b++) {
+            uint64_t h = 1469598103934665603ull;
+            for (uint32_t form = 0; form < 2; form++)
+                for (uint32_t r = 0; r < R; r++) {
+                    uint32_t f1, f2;
+                    const uint32_t r1 = step(r, a, form != 0, f1);
+                    const uint32_t r2 = step(r1, b, form != 0, f2);
+                    const uint32_t v = r2 | (f1 << 2 | f2) << 24;
+                    col[(size_t)form * R + r] = v;
+                    h = (h ^ v) * 1099511628211ull;
+                }
+            uint32_t id = UINT32_MAX;
+            for (uint32_t cand : by_hash[h])
+                if (col_data[cand] == col) { id = cand; break; }
+            if (id == UINT32_MAX) {
+                if (col_data.size() >= max_cols) return false;
+                id = (uint32_t)col_data.size();
+                by_hash[h].push_back(id);
+                col_data.push_back(col);
+            }
+            sym_pair_col[(size_t)a * C + b] = id;
+        }
+    o.ncols = (uint32_t)col_data.size();
+    o.first.assign((size_t)R * o.ncols, 0);
+    o.all.assign((size_t)R * o.ncols, 0);
+    for (uint32_t c = 0; c < o.ncols; c++)
+        for (uint32_t r = 0; r < R; r++) {
+            o.first[(size_t)r * o.ncols + c] = col_data[c][r];
+            o.all[(size_t)r * o.ncols + c] = col_data[c][(size_t)R + r];
+        }
+    o.pair_col.assign(128 * 128, 0);
+    for (unsigned c1 = 0; c1 < 128; c1++)
+        for (unsigned c2 = 0; c2 < 128; c2++) o.pair_col[c1 * 128 + c2] = (uint16_t)sym_pair_col[(size_t)column[c1] * C + column[c2]];
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------ stride-2 lowering
 bool lower_dfa2(const DfaProgram &d, uint32_t max_cols, Dfa2Program &o) {
     o = Dfa2Program();

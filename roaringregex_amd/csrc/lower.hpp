@@ -174,4 +174,18 @@ struct SearchLineProgram {
 };
 bool lower_search_line(const DfaProgram &fwd, const DfaProgram &anchored, uint32_t max_rows, SearchLineProgram &out);
 
+// Stride-2 form of the line-mode search table (the forward pass of the stripe-wise kernel consumes two bytes per dependent
+// lookup, as the match kernel's stride-2 table does): symbols = the table's columns (byte classes, '\n' last), one column
+// per PAIR of symbols, pairs that act alike on every row - in the first-match form AND in the restart form - share one.
+// Entry = next row | events << 24, events = (flags of the first byte) << 2 | flags of the second, flags as the kernel's event
+// words hold them: 0 nothing, 1 the byte was '\n', 2 it completed a match, 3 a match that starts at the restart point.
+// first: after a hit the row is SKIP until the '\n'; all: a hit leads back to the start row (the search goes on behind it).
+struct SearchLine2Program {
+    uint32_t nrows = 0, ncols = 0, start = 0, skip = 0;
+    std::vector<uint16_t> pair_col;         // [128][128]: column of the byte pair (c1, c2); bytes >= 0x80 are stepped as 0x00
+    std::vector<uint32_t> first, all;       // [nrows][ncols]
+};
+// `column`: byte -> column of `s` (256 entries; '\n' -> the last column).  Returns false beyond max_cols distinct pair columns.
+bool lower_search_line2(const SearchLineProgram &s, const uint32_t *column, uint32_t max_cols, SearchLine2Program &out);
+
 }  // namespace rrx

@@ -227,3 +227,77 @@ class SearchLineReplay:
                         s = k
                 return s, end
         return -1, -1
+
+
+class SearchLine2Replay:
+    """The stride-2 form of the stripe-wise search kernel's forward table (rrx_program_words kind 14): [nrows, ncols, start,
+    skip, layout, pair column[128][128], first[nrows][ncols], all[nrows][ncols]], entry = next row | events << 24, events =
+    flags of the first byte << 2 | of the second (1 '\\n', 2 hit, 3 hit that starts at the restart point).  Replayed as
+    search_chunks_kernel steps a line: pairs aligned to even offsets of the TEXT (so a line may begin on the second byte of
+    a pair: `lead` bytes of the previous line, then its '\\n', come first), bytes >= 0x80 stepped as 0x00, a last odd byte
+    paired with 0x00; hits that are not anchored walk the reverse table back (to the line start: first match; to the end of
+    the previous match: all matches)."""
+
+    def __init__(self, words, rev_words):
+        w = np.asarray(words, dtype=np.int64)
+        self.nrows, self.ncols, self.start, self.skip, self.layout = (int(x) for x in w[:5])
+        self.pair = w[5:5 + 128 * 128].reshape(128, 128)
+        n = self.nrows * self.ncols
+        self.first = w[5 + 128 * 128:5 + 128 * 128 + n].reshape(self.nrows, self.ncols)
+        self.all = w[5 + 128 * 128 + n:5 + 128 * 128 + 2 * n].reshape(self.nrows, self.ncols)
+        self.r = DfaReplay(rev_words)
+
+    def events(self, table, text, row):
+        """[(position, flags)] of the bytes of `text` stepped pair by pair from `row`"""
+        out = []
+        t = [c if c < 128 else 0 for c in text]
+        for i in range(0, len(t), 2):
+            c1, c2 = t[i], t[i + 1] if i + 1 < len(t) else 0
+            e = int(table[row, self.pair[c1, c2]])
+            row = e & 0xffffff
+            ev = e >> 24
+            out.append((i, (ev >> 2) & 3))
+            if i + 1 < len(t):
+                out.append((i + 1, ev & 3))
+        return out
+
+    def walk_back(self, line, lo, end):
+        s, st = end, self.r.start
+        for k in range(end - 1, lo - 1, -1):
+            st = int(self.r.next[st, self.r.cls[line[k]]])
+            if st == 0:
+                break
+            if self.r.acc[st]:
+                s = k
+        return s
+
+    def search(self, line, lead=0):
+        """first match of `line`; lead = 0 / 1: the line begins on the first / second byte of a pair"""
+        text = (b"\n" if lead else b"") + bytes(line) + b"\n"
+        row = self.start
+        for pos, f in self.events(self.first, text, row):
+            p = pos - lead
+            if p < 0:
+                assert f == 1
+                continue
+            if f == 1:
+                assert p == len(line)
+                return -1, -1
+            if f:
+                return (0 if f == 3 else self.walk_back(line, 0, p + 1)), p + 1
+        raise AssertionError("no newline event")
+
+    def search_all(self, line, lead=0):
+        text = (b"\n" if lead else b"") + bytes(line) + b"\n"
+        out, lb = [], 0
+        for pos, f in self.events(self.all, text, self.start):
+            p = pos - lead
+            if p < 0:
+                continue
+            if f == 1:
+                assert p == len(line)
+                return out
+            if f:
+                out.append((lb if f == 3 else self.walk_back(line, lb, p + 1), p + 1))
+                lb = p + 1
+        raise AssertionError("no newline event")

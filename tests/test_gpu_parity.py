@@ -1489,14 +1489,15 @@ def test_search_dense_unanchored_matches_against_the_replay():
 
 
 def test_search_with_tables_beyond_the_chunk_kernels_lds():
-    """`[ab]*a[ab]{11}x`: the product table of the stripe-wise search kernel (8193 rows) does not fit a CU's LDS while the plain forward
-    and reverse tables fit the line-per-lane kernels (round 1's path: line offsets, then a lane per line) - first match, all matches
-    and the one-call form against the CPU replay of the two tables."""
+    """`[ab]*a[ab]{11}x`: the product table of the stripe-wise search kernel (8193 rows) does not fit a CU's LDS: the kernel's
+    GLOBAL form (the stride-2 table left in HBM/L2, only the pair table in LDS; rounds 1-3: line offsets, then a lane per line) -
+    first match, all matches and the one-call form against the CPU replay of the two tables, with and without bytes >= 0x80."""
     from program_replay import SearchReplay
     pattern = "[ab]*a[ab]{11}x"
     r = rr.RRegex(pattern)
     line = r.program(rr.PROGRAM_SEARCH_LINE)
-    assert line is None or int(line[0]) * int(line[1]) * 4 > 160 * 1024          # (else this test no longer reaches the fallback)
+    assert line is not None and int(line[0]) * int(line[1]) * 4 > 160 * 1024
+    assert int(r.program(rr.PROGRAM_SEARCH_LINE2)[4]) == 2                      # layout: HBM/L2 (else this test no longer reaches that form)
     rep = SearchReplay(r.program(rr.PROGRAM_SEARCH_FWD), r.program(rr.PROGRAM_SEARCH_REV))
     rng = np.random.default_rng(31)
     data = rng.choice(np.frombuffer(b"abx\n", dtype=np.uint8), size=200_000, p=[0.45, 0.45, 0.07, 0.03]).astype(np.uint8)
@@ -1514,6 +1515,16 @@ def test_search_with_tables_beyond_the_chunk_kernels_lds():
     assert list(zip(st.cpu().tolist(), en.cpu().tolist())) == [m for ms in all_want for m in ms]
     f2, s2, e2 = r.search_all_fused(corpus)
     assert int(f2[-1]) == st.numel() and torch.equal(f2[:-1], first) and torch.equal(s2, st) and torch.equal(e2, en)
+    # bytes >= 0x80 in the text (they cannot index the pair table: the kernel steps them as 0x00)
+    data2 = data.copy()
+    data2[rng.integers(0, data2.size - 1, 400)] = rng.integers(128, 256, 400).astype(np.uint8)
+    lines2 = data2.tobytes()[:-1].split(b"\n")
+    first2 = [rep.search(ln) for ln in lines2]
+    corpus2 = rr.Corpus(torch.from_numpy(data2).cuda())
+    s, e = r.search_corpus(corpus2)
+    assert list(zip(s.cpu().tolist(), e.cpu().tolist())) == first2
+    f3, s3, e3 = r.search_all_fused(corpus2)
+    assert list(zip(s3.cpu().tolist(), e3.cpu().tolist())) == [m for ln in lines2 for m in rep.search_all(ln)]
 
 
 def test_search_all_fused_dense_and_long():

@@ -347,7 +347,7 @@ def test_search_tables_find_the_earliest_ending_leftmost_match():
     """Search has no counterpart in the reference's code; it is pinned to the reference's ACCEPTANCE:
     the oracle tries every substring with whole-string acceptance (smallest end, then smallest start).  The forward
     and reverse tables are replayed on the CPU exactly as the device kernel runs them."""
-    from program_replay import SearchLineReplay, SearchReplay
+    from program_replay import SearchLineReplay, SearchLine2Replay, SearchReplay
     rng = random.Random(31)
     pats = ["ab+c", "a*", "(a|b)*abb", "[0-9]+\\.[0-9]+", "x?y?z?", "k(1|10|100)", "a{2,4}b", ".*c", "c.*", "(ab|b)a?", "[^a]b", EMAIL, U2]
     done = 0
@@ -377,15 +377,25 @@ def test_search_tables_find_the_earliest_ending_leftmost_match():
         lw = r.program(rr.PROGRAM_SEARCH_LINE)               # the stripe-wise kernel's table (absent for patterns that accept "")
         line_rep = SearchLineReplay(lw, rv) if lw is not None else None
         assert (line_rep is None) == o.accepts(""), p
+        l2 = r.program(rr.PROGRAM_SEARCH_LINE2)              # ... and its stride-2 form, what the kernel steps
+        line2_rep = SearchLine2Replay(l2, rv) if l2 is not None else None
+        assert (line2_rep is None) == (line_rep is None), p
+        if line2_rep is not None:
+            assert line2_rep.layout == 1, (p, "these tables fit the LDS")
         for ln, s, e in zip(lines, st, en):
             assert rep.search(ln) == (int(s), int(e)), (p[:50], ln, (int(s), int(e)))
             if line_rep is not None:
                 assert line_rep.search(ln) == (int(s), int(e)), (p[:50], ln, (int(s), int(e)), "line form")
+                for lead in (0, 1):
+                    assert line2_rep.search(ln, lead) == (int(s), int(e)), (p[:50], ln, (int(s), int(e)), "stride-2 line form", lead)
         cnt, ast, aen = o.search_all(b"\n".join(lines) + b"\n")
         k = 0
         for ln, c in zip(lines, cnt):
             want = [(int(ast[k + j]), int(aen[k + j])) for j in range(int(c))]
             assert rep.search_all(ln) == want, (p[:50], ln, want)
+            if line2_rep is not None:
+                for lead in (0, 1):
+                    assert line2_rep.search_all(ln, lead) == want, (p[:50], ln, want, "stride-2 line form", lead)
             k += int(c)
 
 
