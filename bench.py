@@ -44,6 +44,8 @@ WORKLOADS = {
     # automata that do not determinise over text whose live sets are few: the sampled table
     "urltail": ("url", "U2TAIL", 8 << 30, "extra: U2(x|y)*x(x|y){30} over the URL corpus (no DFA within memory: 2^31 sets on x/y text; sampled table)"),
     "urlalt": ("url", "U2ALT", 8 << 30, "extra: (U2)|(x|y)*x(x|y){30} over the URL corpus (no DFA within memory; sampled table)"),
+    # search with a product table beyond the LDS (8193 rows): the stripe-wise search kernel's global form (--search)
+    "abx": ("ablines", "ABX", 1 << 30, "extra: [ab]*a[ab]{11}x over lines of a/b (search tables beyond the LDS)"),
     # the same automata over SHORT lines (30-120 bytes): only the first block of 2048 positions is ever live - sparse sets
     "short5000": ("ablines", "NONDET5000", 1 << 28, "extra: (a|b)*a(a|b){5000} over lines of 30-120 a/b (sparse live sets)"),
     "short16000": ("ablines", "NONDET16000", 1 << 28, "extra: (a|b)*a(a|b){16000} over lines of 30-120 a/b (16003 positions, sparse live sets)"),
@@ -60,7 +62,7 @@ def patterns():
     u2 = [k["pattern"] for k in kat["kat"] if k["pattern"].startswith("(http|https|ftp)")][0]
     k1000 = kat["big_states"][-1]["pattern"]
     return {"U2": u2, "EMAIL": r"[A-Za-z0-9._]+@[A-Za-z0-9.]+", "A300": "a{1,300}", "K1000": k1000, "K1000C": ".*(" + k1000 + ").*",
-            "U2TAIL": u2 + "(x|y)*x(x|y){30}", "U2ALT": "(" + u2 + ")|(x|y)*x(x|y){30}",
+            "ABX": "[ab]*a[ab]{11}x", "U2TAIL": u2 + "(x|y)*x(x|y){30}", "U2ALT": "(" + u2 + ")|(x|y)*x(x|y){30}",
             "NONDET": "(a|b)*a(a|b){40}", "NONDET600": "(a|b)*a(a|b){600}", "NONDET5000": "(a|b)*a(a|b){5000}", "NONDET16000": "(a|b)*a(a|b){16000}"}
 
 

@@ -81,7 +81,11 @@ int         rrx_order_table(rrx_regex *re, const void *sample, uint32_t lanes, u
 /* RRX_OPT_UNITS_PER_WORKGROUP (default 0 = off): the stride-2 batch kernel hands its stripes out in units of 64 inside the
  * workgroup, `value` (16 ... 65536) of them per workgroup of 16 waves, a wave taking its next unit from a counter in LDS.
  * Same results; measured no faster than one stripe per lane on any config (profiles/r04_unit_handout_ab.txt).           */
-enum { RRX_OPT_BACKGROUND_ORDER = 1, RRX_OPT_UNITS_PER_WORKGROUP = 2, RRX_OPT_SAMPLED_TABLE = 3, RRX_OPT_FLUSH_SLOTS = 4 };
+/* RRX_OPT_SEARCH_ANCHORED (default 1): the search kernels' forward table is the product of "any bytes, then the pattern" with
+ * the pattern's own table, which tells the matches that start at the line start (no walk back to find the start); 0 builds the
+ * forward table alone - fewer rows, every match start walked back to - which is also what a product beyond 65534 rows falls
+ * back to.  Same results.  Set it before the regex' first search (RRX_ERR_ARG afterwards).                                  */
+enum { RRX_OPT_BACKGROUND_ORDER = 1, RRX_OPT_UNITS_PER_WORKGROUP = 2, RRX_OPT_SAMPLED_TABLE = 3, RRX_OPT_FLUSH_SLOTS = 4, RRX_OPT_SEARCH_ANCHORED = 5 };
 int         rrx_set_option(rrx_regex *re, int option, int64_t value);
 /* The SAMPLED TABLE (an automaton that does not determinise - AUTO leaves it on the NFA lane engine - over text whose live sets
  * are few, README.md:18-21): the state sets a text sample reaches are interned into a table, every transition the sample and a

@@ -26,6 +26,7 @@ OPT_BACKGROUND_ORDER = 1
 OPT_UNITS_PER_WORKGROUP = 2
 OPT_SAMPLED_TABLE = 3
 OPT_FLUSH_SLOTS = 4
+OPT_SEARCH_ANCHORED = 5
 
 # every symbol include/rrx.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = (
@@ -494,6 +495,11 @@ class RRegex:
     def set_flush_slots(self, slots):
         """rrx_set_option(RRX_OPT_FLUSH_SLOTS): 0 = automatic, or 1 ... 32 slots between two common flushes of the stride-2 kernel."""
         _check(_L.rrx_set_option(self._h, OPT_FLUSH_SLOTS, int(slots)))
+
+    def set_search_anchored(self, enabled):
+        """rrx_set_option(RRX_OPT_SEARCH_ANCHORED): False builds the search kernels' forward table without the product that tells
+        the matches starting at the line start (fewer rows; every match start is walked back to).  Before the first search."""
+        _check(_L.rrx_set_option(self._h, OPT_SEARCH_ANCHORED, 1 if enabled else 0))
 
     def set_units_per_workgroup(self, units):
         """rrx_set_option(RRX_OPT_UNITS_PER_WORKGROUP): the stride-2 batch kernel hands its stripes out in units of 64 inside

@@ -48,8 +48,7 @@ struct ItemsTableOnDevice {
 };
 struct SearchTablesOnDevice {
     void *blob = nullptr;
-    dev::SearchDevice dev;
-    dev::SearchChunkDevice chunk;      // the stripe-wise form (forward table in line mode); nrows = 0: not usable
+    dev::SearchChunkDevice chunk;      // the stripe-wise kernel's tables (device.hpp)
 };
 
 // Small results a call has to hand back to the host (line totals, flags) are written by the call's last kernel into a slot
@@ -113,6 +112,7 @@ struct rrx_regex {
     mutable TableOrderSearch t2_order;                   // the order search, in the background or in the caller of rrx_order_table
     mutable Dfa2OrderStats t2_order_stats;               // (under `mu`)
     std::atomic<int> opt_background_order{1};            // RRX_OPT_BACKGROUND_ORDER
+    std::atomic<int> opt_search_anchored{1};             // RRX_OPT_SEARCH_ANCHORED
     std::atomic<int> opt_units_per_wg{0};                // RRX_OPT_UNITS_PER_WORKGROUP (0: one stripe per lane and launch)
     std::atomic<int> opt_sampled_table{1};               // RRX_OPT_SAMPLED_TABLE
     std::atomic<int> opt_flush_slots{0};                 // RRX_OPT_FLUSH_SLOTS (0: from the corpus' mean line length)
@@ -265,7 +265,7 @@ struct rrx_regex {
     mutable SearchLineProgram search_line;  // stripe-wise form (nrows = 0: not built)
     mutable SearchLine2Program search_line2;    // its stride-2 form, what the stripe-wise kernel runs (nrows = 0: not built)
     mutable dev::SearchChunkDevice chunk_proto; // its layout on the device, without the pointers (nrows = 0: the line-per-lane kernels)
-    mutable bool search_lanes_ok = false;       // the plain forward + reverse tables fit the line-per-lane kernels' LDS
+    mutable bool search_nullable = false;       // the pattern accepts the empty string: every offset is a match, no table (empty_matches)
     mutable std::map<int, SearchTablesOnDevice> search_on_device;
     mutable std::map<int, ItemsTableOnDevice> items_on_device;
     // Scratch of the single-string entries (rrx_match_string / rrx_match_cstr): one grow-only device buffer per device,
@@ -372,22 +372,31 @@ struct rrx_regex {
         return ins.first->second.blob ? &ins.first->second.line : nullptr;
     }
 
-    int build_search() const {           // call with `mu` held
+    // Host side of the search tables (call with `mu` held).  RRX_OK also for a pattern that accepts the empty string: it needs
+    // no table (search_nullable), search_fwd / search_rev are built all the same (rrx_program_words).
+    int build_search() const {
         if (search_state == 0) {
             const Reduced red = reduce(trimmed);
             const bool ok = search_dfas(red, kMaxSubsetStates, search_fwd, search_rev);
-            DfaProgram anchored;
-            if (!(ok && lower_dfa(red, kMaxSubsetStates, anchored) && lower_search_line(search_fwd, anchored, 65534, search_line)))
-                search_line = SearchLineProgram();
+            search_nullable = rrx_accepts_empty(this) != 0;
+            search_line = SearchLineProgram();
             search_line2 = SearchLine2Program();
+            chunk_proto = dev::SearchChunkDevice();
+            if (ok && !search_nullable) {
+                // the product with the anchored table tells the hits whose match starts at the line start (no walk back); a
+                // product beyond the row budget: the forward table alone (every hit walks)
+                DfaProgram anchored;
+                if (!(opt_search_anchored.load() && lower_dfa(red, kMaxSubsetStates, anchored) && lower_search_line(search_fwd, &anchored, 65534, search_line)) &&
+                    !lower_search_line(search_fwd, nullptr, 65534, search_line))
+                    search_line = SearchLineProgram();
+            }
             if (search_line.nrows) {
                 uint32_t column[256];
                 for (int c = 0; c < 256; c++) column[c] = c == '\n' ? search_line.ncols - 1 : search_fwd.cls[c];
                 if (!lower_search_line2(search_line, column, 16383, search_line2)) search_line2 = SearchLine2Program();
             }
             // the stripe-wise kernel's layout of that table: LDS if it fits beside the reverse table, the job pools and a result
-            // window, else HBM/L2 (device.hpp: SearchChunkDevice); neither: the line-per-lane kernels, if THEIR tables fit
-            chunk_proto = dev::SearchChunkDevice();
+            // window, else HBM/L2 (device.hpp: SearchChunkDevice)
             const SearchLine2Program &s2 = search_line2;
             if (s2.nrows && search_fwd.ncls < 128) {
                 dev::SearchChunkDevice c;
@@ -403,35 +412,33 @@ struct rrx_regex {
                 }
                 if (fits) chunk_proto = c;
             }
-            dev::SearchDevice probe;
-            probe.nf = search_fwd.nstates; probe.nr = search_rev.nstates; probe.ncls = search_fwd.ncls;
-            search_lanes_ok = ok && dev::search_lds_bytes(probe) <= dev::kSearchLdsBudget && probe.nf <= 32767 && probe.nr <= 32767;
-            search_state = ok && (search_lanes_ok || chunk_proto.nrows) ? 1 : -1;
+            search_state = ok && (search_nullable || chunk_proto.nrows) ? 1 : -1;
         }
-        return search_state == 1 ? RRX_OK : fail(RRX_ERR_UNSUPPORTED, "search tables too large for the device (forward + reverse DFA must fit 64 KiB of LDS)");
+        return search_state == 1 ? RRX_OK
+                                 : fail(RRX_ERR_UNSUPPORTED, "search tables too large for the device (the reverse DFA must fit 64 KiB of LDS, the forward "
+                                                              "product table 65534 rows and 256 MiB)");
     }
-    int search_tables(int device, const dev::SearchDevice **out) const {
+    // The stripe-wise kernel's tables on `device` (uploaded once); *out = nullptr for a pattern that accepts the empty string.
+    int search_tables(int device, const dev::SearchChunkDevice **out) const {
         std::lock_guard<std::mutex> lock(mu);
         int rc = build_search();
         if (rc) return rc;
+        *out = nullptr;
+        if (search_nullable) return RRX_OK;
         auto it = search_on_device.find(device);
-        if (it != search_on_device.end()) { *out = &it->second.dev; return RRX_OK; }
+        if (it != search_on_device.end()) { *out = &it->second.chunk; return RRX_OK; }
         HIP_TRY(hipSetDevice(device));
         std::vector<uint8_t> host;
         auto put = [&](const void *p, size_t n) { size_t off = (host.size() + 15) & ~(size_t)15; host.resize(off + n); std::memcpy(host.data() + off, p, n); return off; };
         const size_t oC = put(search_fwd.cls, 256);
-        const size_t oNF = put(search_fwd.next.data(), search_fwd.next.size() * 2), oNR = put(search_rev.next.data(), search_rev.next.size() * 2);
-        const size_t oAF = put(search_fwd.accepting.data(), search_fwd.accepting.size()), oAR = put(search_rev.accepting.data(), search_rev.accepting.size());
         SearchTablesOnDevice t;
-        // The stripe-wise form: the line-mode product table in its stride-2 form (lower_search_line2), laid out for LDS (16-bit
-        // entries, a byte-wide pair table) when it fits beside the reverse table, the job pools and a result window, and for
-        // HBM/L2 (32-bit entries, a 16-bit pair table in LDS) when it does not (device.hpp: SearchChunkDevice).
+        // The line-mode product table in its stride-2 form (lower_search_line2), laid out for LDS (16-bit entries, a byte-wide
+        // pair table) or for HBM/L2 (32-bit entries, a 16-bit pair table in LDS): device.hpp, SearchChunkDevice.
         size_t oP = 0, oT = 0, oTA = 0, oRV = 0;
         const uint32_t K = search_fwd.ncls, NR = search_rev.nstates;
         const SearchLine2Program &s2 = search_line2;
-        const bool line_form = chunk_proto.nrows != 0;
         t.chunk = chunk_proto;
-        if (line_form && !t.chunk.in_global) {
+        if (!t.chunk.in_global) {
             const uint32_t rb = t.chunk.row_bytes, br = t.chunk.base_row;
             std::vector<uint8_t> p8(dev::kSearchP8Bytes, 0);
             for (unsigned c1 = 0; c1 < 128; c1++)
@@ -449,7 +456,7 @@ struct rrx_regex {
             oP = put(p8.data(), p8.size());
             oT = put(T.data(), T.size() * 2);
             oTA = put(TA.data(), TA.size() * 2);
-        } else if (line_form) {
+        } else {
             std::vector<uint16_t> p16((size_t)128 * dev::kSearchP16Stride, 0);
             for (unsigned c1 = 0; c1 < 128; c1++)
                 for (unsigned c2 = 0; c2 < 128; c2++) p16[c1 * dev::kSearchP16Stride + c2] = (uint16_t)(4 * s2.pair_col[c1 * 128 + c2]);
@@ -463,7 +470,7 @@ struct rrx_regex {
             oT = put(T.data(), T.size() * 4);
             oTA = put(TA.data(), TA.size() * 4);
         }
-        if (line_form) {
+        {
             std::vector<uint16_t> rv(((size_t)NR * K + 1) & ~(size_t)1, 0);
             for (size_t i = 0; i < (size_t)NR * K; i++) { const uint16_t nx = search_rev.next[i]; rv[i] = (uint16_t)(nx | (search_rev.accepting[nx] ? 0x8000u : 0u)); }
             oRV = put(rv.data(), rv.size() * 2);
@@ -472,31 +479,18 @@ struct rrx_regex {
         hipError_t e = hipMemcpy(t.blob, host.data(), host.size(), hipMemcpyHostToDevice);
         if (e != hipSuccess) { (void)hipFree(t.blob); return hip_fail(e, "search table upload"); }
         const uint8_t *base = static_cast<const uint8_t *>(t.blob);
-        t.dev.nf = search_fwd.nstates; t.dev.nr = search_rev.nstates; t.dev.ncls = search_fwd.ncls;
-        t.dev.start_f = search_fwd.start; t.dev.start_r = search_rev.start;
-        t.dev.cls = base + oC;
-        t.dev.next_f = reinterpret_cast<const uint16_t *>(base + oNF); t.dev.next_r = reinterpret_cast<const uint16_t *>(base + oNR);
-        t.dev.acc_f = base + oAF; t.dev.acc_r = base + oAR;
-        if (line_form) {
-            if (t.chunk.in_global) {
-                t.chunk.P16 = reinterpret_cast<const uint16_t *>(base + oP);
-                t.chunk.G2 = reinterpret_cast<const uint32_t *>(base + oT); t.chunk.G2_all = reinterpret_cast<const uint32_t *>(base + oTA);
-            } else {
-                t.chunk.P8 = base + oP;
-                t.chunk.T2 = reinterpret_cast<const uint16_t *>(base + oT); t.chunk.T2_all = reinterpret_cast<const uint16_t *>(base + oTA);
-            }
-            t.chunk.rev = reinterpret_cast<const uint16_t *>(base + oRV);
-            t.chunk.cls = base + oC;
+        if (t.chunk.in_global) {
+            t.chunk.P16 = reinterpret_cast<const uint16_t *>(base + oP);
+            t.chunk.G2 = reinterpret_cast<const uint32_t *>(base + oT); t.chunk.G2_all = reinterpret_cast<const uint32_t *>(base + oTA);
+        } else {
+            t.chunk.P8 = base + oP;
+            t.chunk.T2 = reinterpret_cast<const uint16_t *>(base + oT); t.chunk.T2_all = reinterpret_cast<const uint16_t *>(base + oTA);
         }
+        t.chunk.rev = reinterpret_cast<const uint16_t *>(base + oRV);
+        t.chunk.cls = base + oC;
         auto ins = search_on_device.emplace(device, t);
-        *out = &ins.first->second.dev;
+        *out = &ins.first->second.chunk;
         return RRX_OK;
-    }
-    // the stripe-wise form of the same tables, or nullptr if they do not admit it (call after search_tables succeeded)
-    const dev::SearchChunkDevice *search_chunk_tables(int device) const {
-        std::lock_guard<std::mutex> lock(mu);
-        auto it = search_on_device.find(device);
-        return it != search_on_device.end() && it->second.chunk.nrows ? &it->second.chunk : nullptr;
     }
 
     // Upload the program for `device` once; returns the device-side descriptors.
@@ -844,6 +838,12 @@ int rrx_set_option(rrx_regex *re, int option, int64_t value) {
         return RRX_OK;
     }
     if (option == RRX_OPT_SAMPLED_TABLE) { re->opt_sampled_table.store(value ? 1 : 0); return RRX_OK; }
+    if (option == RRX_OPT_SEARCH_ANCHORED) {
+        std::lock_guard<std::mutex> lock(re->mu);
+        if (re->search_state != 0) return fail(RRX_ERR_ARG, "the search tables of this regex are built already");
+        re->opt_search_anchored.store(value ? 1 : 0);
+        return RRX_OK;
+    }
     if (option == RRX_OPT_UNITS_PER_WORKGROUP) {
         if (value < 0 || value > 65536) return fail(RRX_ERR_ARG, "units per workgroup: 0 (off) or 16 ... 65536");
         re->opt_units_per_wg.store(value && value < 16 ? 16 : (int)value);
@@ -1185,90 +1185,80 @@ static int chunk_index(const rrx_corpus *c, void *stream) {
 
 int rrx_search_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_start, uint32_t *d_end, void *stream) {
     if (!re || !c || (c->nlines && (!d_start || !d_end))) return fail(RRX_ERR_ARG, "null argument");
-    if (rrx_accepts_empty(re)) {
-        // the pattern accepts the empty string: the accepted substring with the smallest end is [0, 0) in every string - no
-        // table, no line offsets (round 2 built the per-line offset array for this: 10 ms per 8 GiB), two fills
-        HIP_TRY(hipSetDevice(c->device));
-        if (c->nlines) {
-            HIP_TRY(hipMemsetAsync(d_start, 0, c->nlines * sizeof(uint32_t), (hipStream_t)stream));
-            HIP_TRY(hipMemsetAsync(d_end, 0, c->nlines * sizeof(uint32_t), (hipStream_t)stream));
-        }
-        return RRX_OK;
-    }
-    const dev::SearchDevice *t;
-    int rc = re->search_tables(c->device, &t);
+    const dev::SearchChunkDevice *ct;
+    int rc = re->search_tables(c->device, &ct);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
     if (!c->nlines) return RRX_OK;
-    if (const dev::SearchChunkDevice *ct = re->search_chunk_tables(c->device)) {     // stripe-wise: one pass, coalesced results
-        rc = chunk_index(c, stream);
-        if (rc) return rc;
-        int e = dev::search_chunks(*ct, c->has_high, c->d_bytes, c->nbytes, c->d_chunk_base, c->nchunks, d_start, d_end, stream);
-        if (e) return hip_fail((hipError_t)e, "search_chunks launch");
+    if (!ct) {
+        // the pattern accepts the empty string: the accepted substring with the smallest end is [0, 0) in every string - no
+        // table, no line offsets, two fills
+        HIP_TRY(hipMemsetAsync(d_start, 0, c->nlines * sizeof(uint32_t), (hipStream_t)stream));
+        HIP_TRY(hipMemsetAsync(d_end, 0, c->nlines * sizeof(uint32_t), (hipStream_t)stream));
         return RRX_OK;
     }
-    rc = line_offsets(c, stream);
+    rc = chunk_index(c, stream);
     if (rc) return rc;
-    int e = dev::search_lines(*t, c->d_bytes, c->nbytes, c->d_line_off, c->nlines, d_start, d_end, stream);
-    if (e) return hip_fail((hipError_t)e, "search_lines launch");
+    int e = dev::search_chunks(*ct, c->has_high, c->d_bytes, c->nbytes, c->d_chunk_base, c->nchunks, d_start, d_end, stream);
+    if (e) return hip_fail((hipError_t)e, "search_chunks launch");
     return RRX_OK;
 }
 
 int rrx_search_all_count(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_count, void *stream) {
     if (!re || !c || (c->nlines && !d_count)) return fail(RRX_ERR_ARG, "null argument");
-    const dev::SearchDevice *t;
-    int rc = re->search_tables(c->device, &t);
+    const dev::SearchChunkDevice *ct;
+    int rc = re->search_tables(c->device, &ct);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
     if (!c->nlines) return RRX_OK;
-    if (const dev::SearchChunkDevice *ct = re->search_chunk_tables(c->device)) {     // stripe-wise
-        rc = chunk_index(c, stream);
+    if (!ct) {                                                       // accepts "": a match at every offset of the line, its end included
+        rc = line_offsets(c, stream);
         if (rc) return rc;
-        int e = dev::search_chunks_count(*ct, c->has_high, c->d_bytes, c->nbytes, c->d_chunk_base, c->nchunks, d_count, stream);
-        if (e) return hip_fail((hipError_t)e, "search_chunks_count launch");
+        int e = dev::empty_matches(c->d_line_off, c->nlines, d_count, nullptr, nullptr, nullptr, stream);
+        if (e) return hip_fail((hipError_t)e, "empty_matches launch");
         return RRX_OK;
     }
-    rc = line_offsets(c, stream);
+    rc = chunk_index(c, stream);
     if (rc) return rc;
-    int e = dev::search_all(*t, c->d_bytes, c->nbytes, c->d_line_off, c->nlines, d_count, nullptr, nullptr, nullptr, stream);
-    if (e) return hip_fail((hipError_t)e, "search_all launch");
+    int e = dev::search_chunks_count(*ct, c->has_high, c->d_bytes, c->nbytes, c->d_chunk_base, c->nchunks, d_count, stream);
+    if (e) return hip_fail((hipError_t)e, "search_chunks_count launch");
     return RRX_OK;
 }
 
 int rrx_search_all_fill(const rrx_regex *re, const rrx_corpus *c, const uint64_t *d_first, uint32_t *d_start, uint32_t *d_end, void *stream) {
     if (!re || !c || (c->nlines && (!d_first || !d_start || !d_end))) return fail(RRX_ERR_ARG, "null argument");
-    const dev::SearchDevice *t;
-    int rc = re->search_tables(c->device, &t);
+    const dev::SearchChunkDevice *ct;
+    int rc = re->search_tables(c->device, &ct);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
     if (!c->nlines) return RRX_OK;
-    if (const dev::SearchChunkDevice *ct = re->search_chunk_tables(c->device)) {     // stripe-wise
-        rc = chunk_index(c, stream);
+    if (!ct) {
+        rc = line_offsets(c, stream);
         if (rc) return rc;
-        int e = dev::search_chunks_fill(*ct, c->has_high, c->d_bytes, c->nbytes, c->d_chunk_base, c->nchunks, d_first, d_start, d_end, stream);
-        if (e) return hip_fail((hipError_t)e, "search_chunks_fill launch");
+        int e = dev::empty_matches(c->d_line_off, c->nlines, nullptr, d_first, d_start, d_end, stream);
+        if (e) return hip_fail((hipError_t)e, "empty_matches launch");
         return RRX_OK;
     }
-    rc = line_offsets(c, stream);
+    rc = chunk_index(c, stream);
     if (rc) return rc;
-    int e = dev::search_all(*t, c->d_bytes, c->nbytes, c->d_line_off, c->nlines, nullptr, d_first, d_start, d_end, stream);
-    if (e) return hip_fail((hipError_t)e, "search_all launch");
+    int e = dev::search_chunks_fill(*ct, c->has_high, c->d_bytes, c->nbytes, c->d_chunk_base, c->nchunks, d_first, d_start, d_end, stream);
+    if (e) return hip_fail((hipError_t)e, "search_chunks_fill launch");
     return RRX_OK;
 }
 
-// count + fill in one call.  Stripe-wise tables: one launch (decoupled look-back over the chunks' match counts).  Otherwise
-// the two passes of the older kernels with a device scan between them.
+// count + fill in one call: one launch (decoupled look-back over the chunks' match counts).  A pattern that accepts the empty
+// string: the line lengths, a device scan, a fill.
 int rrx_search_all(const rrx_regex *re, const rrx_corpus *c, uint64_t *d_first, uint32_t *d_start, uint32_t *d_end, size_t cap, size_t *total,
                    void *stream) {
     if (!re || !c || !total || !d_first || (cap && (!d_start || !d_end))) return fail(RRX_ERR_ARG, "null argument");
     *total = 0;
-    const dev::SearchDevice *t;
-    int rc = re->search_tables(c->device, &t);
+    const dev::SearchChunkDevice *ct;
+    int rc = re->search_tables(c->device, &ct);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(c->device));
     hipStream_t st = (hipStream_t)stream;
     if (!c->nlines) { HIP_TRY(hipMemsetAsync(d_first, 0, sizeof(uint64_t), st)); HIP_TRY(hipStreamSynchronize(st)); return RRX_OK; }
-    if (const dev::SearchChunkDevice *ct = re->search_chunk_tables(c->device)) {
+    if (ct) {
         rc = chunk_index(c, stream);
         if (rc) return rc;
         const size_t sb = dev::search_all_scratch_bytes(c->nchunks);
@@ -1287,17 +1277,18 @@ int rrx_search_all(const rrx_regex *re, const rrx_corpus *c, uint64_t *d_first, 
         *total = (size_t)tail[0];
         return RRX_OK;
     }
-    // lane = line kernels: count, scan on the device, fill
+    // accepts "": count (line length + 1), scan on the device, fill
+    rc = line_offsets(c, stream);
+    if (rc) return rc;
     uint32_t *d_count = nullptr;
     HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d_count), (c->nlines + 1) * sizeof(uint32_t)));
     uint64_t *d_sums = nullptr;
     hipError_t he = hipMalloc(reinterpret_cast<void **>(&d_sums), dev::scan_scratch_words(c->nlines) * sizeof(uint64_t));
     if (he != hipSuccess) { (void)hipFree(d_count); return hip_fail(he, "hipMalloc"); }
     auto done = [&](int code) { (void)hipFree(d_count); (void)hipFree(d_sums); return code; };
-    rc = rrx_search_all_count(re, c, d_count, stream);
-    if (rc) return done(rc);
-    int e = dev::scan_counts(d_count, d_first, d_sums, c->nlines, stream);      // d_first[nlines] = total
-    if (e) return done(hip_fail((hipError_t)e, "scan launch"));
+    int e = dev::empty_matches(c->d_line_off, c->nlines, d_count, nullptr, nullptr, nullptr, stream);
+    if (!e) e = dev::scan_counts(d_count, d_first, d_sums, c->nlines, stream);  // d_first[nlines] = total
+    if (e) return done(hip_fail((hipError_t)e, "empty_matches / scan launch"));
     he = hipMemsetAsync(d_first, 0, sizeof(uint64_t), st);                      // the scan marks entry 0 as a stripe start: not here
     uint64_t tot = 0;
     if (he == hipSuccess) he = hipMemcpyAsync(&tot, d_first + c->nlines, sizeof tot, hipMemcpyDeviceToHost, st);
@@ -1305,11 +1296,8 @@ int rrx_search_all(const rrx_regex *re, const rrx_corpus *c, uint64_t *d_first, 
     if (he != hipSuccess) return done(hip_fail(he, "search_all scan"));
     *total = (size_t)tot;
     if (tot && cap) {                                                            // matches beyond `cap` are counted, not written (as rrx.h says)
-        rc = line_offsets(c, stream);
-        if (!rc) {
-            e = dev::search_all(*t, c->d_bytes, c->nbytes, c->d_line_off, c->nlines, nullptr, d_first, d_start, d_end, stream, cap);
-            if (e) rc = hip_fail((hipError_t)e, "search_all launch");
-        }
+        e = dev::empty_matches(c->d_line_off, c->nlines, nullptr, d_first, d_start, d_end, stream, cap);
+        if (e) rc = hip_fail((hipError_t)e, "empty_matches launch");
         if (!rc) { he = hipStreamSynchronize(st); if (he != hipSuccess) rc = hip_fail(he, "search_all fill"); }
     }
     return done(rc);

@@ -194,17 +194,9 @@ int match_stripes_wave_nfa(const WaveNfaDevice &p, const uint8_t *bytes, size_t 
 int match_extents_wave_nfa(const WaveNfaDevice &p, const uint8_t *bytes, const uint64_t *off, size_t nitems, uint32_t trim,
                            uint8_t *accept, void *stream);
 
-// items i = bytes[off[i] .. off[i+1] - trim) ; trim = 1 drops a trailing delimiter byte per item
-// Search (the reference has acceptance only): two plain DFAs over the same byte classes.  fwd = "any bytes, then the
-// pattern" (never dies; accepting where some match ends), rev = the pattern read right to left (accepting, walking back
-// from a match end, where a match starts).  Per line: the match [s, e) with the smallest e, then the smallest s.
-struct SearchDevice {
-    uint32_t nf = 0, nr = 0, ncls = 0, start_f = 0, start_r = 0;
-    const uint8_t *cls = nullptr;                // [256]
-    const uint16_t *next_f = nullptr, *next_r = nullptr;     // [n][ncls]
-    const uint8_t *acc_f = nullptr, *acc_r = nullptr;        // [n]
-};
-constexpr uint32_t kSearchLdsBudget = 64 * 1024;
+// Search (the reference has acceptance only).  Per line: the match [s, e) with the smallest e, then the smallest s.
+// Host tables: fwd = "any bytes, then the pattern" (never dies; accepting where some match ends), rev = the pattern read right to
+// left (accepting, walking back from a match end, where a match starts).
 // Stripe-wise search (kernels_search.hip).  The forward table is the LINE MODE product table (lower_search_line: one row per
 // reachable pair of states plus the SKIP row - the line's first match has been found: wait for '\n' -, one column per byte
 // class plus the '\n' column) in its STRIDE-2 form (lower_search_line2): one dependent lookup consumes two bytes and yields
@@ -246,19 +238,14 @@ int search_chunks_fill(const SearchChunkDevice &p, bool clean, const uint8_t *by
 size_t search_all_scratch_bytes(size_t nchunks);
 int search_chunks_all(const SearchChunkDevice &p, bool clean, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks, size_t nlines,
                       uint64_t *first, uint32_t *match_start, uint32_t *match_end, size_t cap, void *scratch, void *stream);
-size_t search_lds_bytes(const SearchDevice &p);
-// line_off[i] = offset of the first byte of line i (built once per corpus from the stripe index); nlines + 1 entries are
-// the caller's to size, entry nlines is written only when the corpus ends in '\n'.
+// line_off[i] = offset of the first byte of line i (built once per corpus from the stripe index; only patterns that accept
+// the empty string need it); nlines + 1 entries are the caller's to size, entry nlines is written only when the corpus ends in '\n'.
 int build_line_offsets(const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base, size_t nstripes,
                        uint64_t *line_off, void *stream);
-// one lane per line: line i = bytes[line_off[i] .. line_off[i+1] - 1)
-int search_lines(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *line_off, size_t nlines,
-                 uint32_t *match_start, uint32_t *match_end, void *stream);
-
-// all matches per line: first == nullptr counts (count[i]); otherwise fills the slots first[i], first[i] + 1, ...
-// (fill: slots >= cap are not written)
-int search_all(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *line_off, size_t nlines, uint32_t *count,
-               const uint64_t *first, uint32_t *match_start, uint32_t *match_end, void *stream, size_t cap = ~(size_t)0);
+// all matches of a pattern that accepts "": [k, k) for k = 0 .. length of the line.  first == nullptr: count[i]; otherwise the
+// slots first[i], first[i] + 1, ... are filled (slots >= cap are not written)
+int empty_matches(const uint64_t *line_off, size_t nlines, uint32_t *count, const uint64_t *first, uint32_t *match_start, uint32_t *match_end,
+                  void *stream, size_t cap = ~(size_t)0);
 
 // One long string (regex.h:156-159 consumes it byte by byte): the string is cut into chunks, every chunk is stepped
 // from EVERY table state at once (lane = (chunk, start state); the lanes of a chunk read the same text), which yields

@@ -787,13 +787,11 @@ __global__ __launch_bounds__(256) void scan_chunks_kernel(const uint32_t *__rest
     }
 }
 
-// ============================================================================================ search
-// Two kernels.  line_offsets_kernel (once per corpus): lane = stripe, every '\n' at p inside the stripe starts the next
-// line at p + 1 (line numbers from the stripe index).  search_lines_kernel: lane = line.  Step the forward DFA until it
-// accepts (that is the smallest match end e) and stop there - a lane never reads the rest of its line - then walk the
-// reverse DFA back from e to the line start, remembering the last position where it accepts (the smallest start of a
-// match that ends at e).  Consecutive lanes own consecutive lines: their text is contiguous and both result arrays are
-// written coalesced.
+// ============================================================================================ search: patterns that accept ""
+// The stripe-wise kernels (kernels_search.hip) serve every pattern that does not accept the empty string.  One that does has
+// a match [k, k) at EVERY offset k = 0 .. length of its line (the search moves on by one byte after an empty match), whatever
+// the text: no table, only the line lengths.  line_offsets_kernel (once per corpus): lane = stripe, every '\n' at p inside the
+// stripe starts the next line at p + 1 (line numbers from the stripe index).  empty_matches_kernel: lane = line.
 __global__ __launch_bounds__(256) void line_offsets_kernel(const uint8_t *__restrict__ bytes, size_t nbytes, uint32_t stripe,
                                                            const uint64_t *__restrict__ stripe_base, size_t nstripes,
                                                            uint64_t *__restrict__ line_off) {
@@ -821,94 +819,17 @@ __global__ __launch_bounds__(256) void line_offsets_kernel(const uint8_t *__rest
         if (bytes[pos] == '\n') line_off[++line] = pos + 1;
 }
 
-struct SearchTables {
-    const uint8_t *cls;
-    const uint16_t *next_f, *next_r;                     // bit 15 of an entry = the state it leads to is accepting
-    uint32_t K, start_f, start_r;
-    bool empty_matches;
-    __device__ void load(const SearchDevice &p, uint8_t *lds) {
-        uint16_t *nf = reinterpret_cast<uint16_t *>(lds);
-        uint16_t *nr = nf + (size_t)p.nf * p.ncls;
-        uint8_t *c = reinterpret_cast<uint8_t *>(nr + (size_t)p.nr * p.ncls);
-        for (uint32_t i = threadIdx.x; i < p.nf * p.ncls; i += blockDim.x) { const uint16_t t = p.next_f[i]; nf[i] = (uint16_t)(t | (p.acc_f[t] ? 0x8000u : 0u)); }
-        for (uint32_t i = threadIdx.x; i < p.nr * p.ncls; i += blockDim.x) { const uint16_t t = p.next_r[i]; nr[i] = (uint16_t)(t | (p.acc_r[t] ? 0x8000u : 0u)); }
-        for (uint32_t i = threadIdx.x; i < 256; i += blockDim.x) c[i] = p.cls[i];
-        cls = c; next_f = nf; next_r = nr; K = p.ncls; start_f = p.start_f; start_r = p.start_r;
-        empty_matches = p.acc_f[p.start_f] != 0;
-    }
-};
-// First match of bytes[p, b) whose start is >= p: false if there is none.  s, e are absolute offsets.
-__device__ __forceinline__ bool search_from(const SearchTables &t, const uint8_t *__restrict__ bytes, size_t nbytes, size_t p, size_t b,
-                                            size_t &s, size_t &e) {
-    if (t.empty_matches) { s = p; e = p; return true; }          // the pattern accepts "": the match is [p, p)
-    uint32_t q = t.start_f;
-    size_t pos = p;
-    bool found = false;
-    while (pos < b && !found) {                                   // aligned dwords; bytes before `pos` / from `b` on are skipped
-        const size_t base = pos & ~(size_t)3;
-        uint32_t w;
-        if (base + 4 <= nbytes) w = *reinterpret_cast<const uint32_t *>(bytes + base);
-        else { w = 0; for (size_t k = pos; k < nbytes; k++) w |= (uint32_t)bytes[k] << (8 * (k - base)); }     // last dword of the data
-        const size_t stop = base + 4 < b ? base + 4 : b;
-        for (; pos < stop; pos++) {
-            const uint32_t x = t.next_f[q * t.K + t.cls[(w >> (8 * (pos - base))) & 0xffu]];
-            q = x & 0x7fffu;
-            if (x & 0x8000u) { found = true; pos++; break; }
-        }
-    }
-    if (!found) return false;
-    e = pos;
-    uint32_t r = t.start_r;
-    size_t best = pos;
-    for (size_t k = pos; k > p;) {
-        k--;
-        const uint32_t x = t.next_r[r * t.K + t.cls[bytes[k]]];
-        r = x & 0x7fffu;
-        if (!r) break;                                            // state 0 is dead
-        if (x & 0x8000u) best = k;
-    }
-    s = best;
-    return true;
-}
-__global__ __launch_bounds__(256) void search_lines_kernel(SearchDevice prog, const uint8_t *__restrict__ bytes, size_t nbytes,
-                                                           const uint64_t *__restrict__ line_off, size_t nlines,
-                                                           uint32_t *__restrict__ match_start, uint32_t *__restrict__ match_end) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    SearchTables t;
-    t.load(prog, smem);
-    __syncthreads();
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nlines) return;
-    const size_t a = line_off[i], b = line_off[i + 1] - 1;        // [a, b): the line without its '\n'
-    size_t s, e;
-    const bool found = search_from(t, bytes, nbytes, a, b, s, e);
-    match_start[i] = found ? (uint32_t)(s - a) : 0xffffffffu;
-    match_end[i] = found ? (uint32_t)(e - a) : 0xffffffffu;
-}
-// All matches of a line, left to right: after a match the search continues at its end (one byte further after an empty
-// match).  FILL = false: count[i] = number of matches.  FILL = true: the matches of line i go to slots first[i], ...
+// FILL = false: count[i] = length of line i + 1.  FILL = true: the matches of line i go to the slots first[i], first[i] + 1, ...
 template <bool FILL>
-__global__ __launch_bounds__(256) void search_all_kernel(SearchDevice prog, const uint8_t *__restrict__ bytes, size_t nbytes,
-                                                         const uint64_t *__restrict__ line_off, size_t nlines,
-                                                         uint32_t *__restrict__ count, const uint64_t *__restrict__ first,
-                                                         uint32_t *__restrict__ match_start, uint32_t *__restrict__ match_end, uint64_t cap) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    SearchTables t;
-    t.load(prog, smem);
-    __syncthreads();
+__global__ __launch_bounds__(256) void empty_matches_kernel(const uint64_t *__restrict__ line_off, size_t nlines, uint32_t *__restrict__ count,
+                                                            const uint64_t *__restrict__ first, uint32_t *__restrict__ match_start,
+                                                            uint32_t *__restrict__ match_end, uint64_t cap) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nlines) return;
-    const size_t a = line_off[i], b = line_off[i + 1] - 1;
-    uint64_t slot = FILL ? first[i] : 0;
-    uint32_t k = 0;
-    for (size_t p = a; p <= b;) {
-        size_t s, e;
-        if (!search_from(t, bytes, nbytes, p, b, s, e)) break;
-        if (FILL && slot + k < cap) { match_start[slot + k] = (uint32_t)(s - a); match_end[slot + k] = (uint32_t)(e - a); }
-        k++;
-        p = e > s ? e : e + 1;
-    }
-    if (!FILL) count[i] = k;
+    const uint64_t len = line_off[i + 1] - 1 - line_off[i];      // the line without its '\n'
+    if (!FILL) { count[i] = (uint32_t)(len + 1); return; }
+    const uint64_t slot = first[i];
+    for (uint64_t k = 0; k <= len && slot + k < cap; k++) { match_start[slot + k] = (uint32_t)k; match_end[slot + k] = (uint32_t)k; }
 }
 
 // ============================================================================================ explicit items, stripe-wise
@@ -1467,7 +1388,6 @@ int mail_results(const uint64_t *total, const uint32_t *flags, const uint8_t *la
     hipLaunchKernelGGL(mail_results_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, total, flags, last_byte, mail);
     return (int)hipGetLastError();
 }
-size_t search_lds_bytes(const SearchDevice &p) { return ((size_t)p.nf + p.nr) * p.ncls * sizeof(uint16_t) + 256; }
 int build_line_offsets(const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base, size_t nstripes,
                        uint64_t *line_off, void *stream) {
     if (!nstripes) return 0;
@@ -1475,31 +1395,12 @@ int build_line_offsets(const uint8_t *bytes, size_t nbytes, uint32_t stripe, con
                        stripe_base, nstripes, line_off);
     return (int)hipGetLastError();
 }
-int search_lines(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *line_off, size_t nlines, uint32_t *match_start,
-                 uint32_t *match_end, void *stream) {
+int empty_matches(const uint64_t *line_off, size_t nlines, uint32_t *count, const uint64_t *first, uint32_t *match_start, uint32_t *match_end,
+                  void *stream, size_t cap) {
     if (!nlines) return 0;
-    const size_t lds = search_lds_bytes(p);
-    if (lds > kSearchLdsBudget || p.nf > 32767 || p.nr > 32767) return (int)hipErrorInvalidValue;
-    static LdsAttr attr;
-    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(search_lines_kernel), lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(search_lines_kernel, dim3((unsigned)((nlines + 255) / 256)), dim3(256), lds, (hipStream_t)stream, p, bytes, nbytes, line_off, nlines,
-                       match_start, match_end);
-    return (int)hipGetLastError();
-}
-int search_all(const SearchDevice &p, const uint8_t *bytes, size_t nbytes, const uint64_t *line_off, size_t nlines, uint32_t *count,
-               const uint64_t *first, uint32_t *match_start, uint32_t *match_end, void *stream, size_t cap) {
-    if (!nlines) return 0;
-    const size_t lds = search_lds_bytes(p);
-    if (lds > kSearchLdsBudget || p.nf > 32767 || p.nr > 32767) return (int)hipErrorInvalidValue;
-    const bool fill = first != nullptr;
-    static LdsAttr attr_fill, attr_count;
-    hipError_t e = fill ? ensure_dynamic_lds(attr_fill, reinterpret_cast<const void *>(search_all_kernel<true>), lds)
-                        : ensure_dynamic_lds(attr_count, reinterpret_cast<const void *>(search_all_kernel<false>), lds);
-    if (e != hipSuccess) return (int)e;
     const dim3 grid((unsigned)((nlines + 255) / 256));
-    if (fill) hipLaunchKernelGGL(search_all_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, p, bytes, nbytes, line_off, nlines, count, first, match_start, match_end, (uint64_t)cap);
-    else hipLaunchKernelGGL(search_all_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, p, bytes, nbytes, line_off, nlines, count, first, match_start, match_end, (uint64_t)cap);
+    if (first) hipLaunchKernelGGL(empty_matches_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, line_off, nlines, count, first, match_start, match_end, (uint64_t)cap);
+    else hipLaunchKernelGGL(empty_matches_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, line_off, nlines, count, first, match_start, match_end, (uint64_t)cap);
     return (int)hipGetLastError();
 }
 static uint32_t long_chunk(size_t nbytes) {

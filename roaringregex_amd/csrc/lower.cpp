@@ -1126,10 +1126,14 @@ bool search_dfas(const Reduced &r, uint32_t max_states, DfaProgram &fwd, DfaProg
 // Line-mode search table: the product of the sticky forward table (where does the first match END) and the anchored table
 // of the pattern itself (is the line's prefix up to here accepted: then the match STARTS at the line start and no walk back
 // is needed).  Rows = reachable pairs + SKIP (last), columns = byte classes + '\n' (last).
-bool lower_search_line(const DfaProgram &fwd, const DfaProgram &anch, uint32_t max_rows, SearchLineProgram &o) {
+bool lower_search_line(const DfaProgram &fwd, const DfaProgram *anchored, uint32_t max_rows, SearchLineProgram &o) {
     o = SearchLineProgram();
     const uint32_t K = fwd.ncls;
-    if (anch.ncls != K || fwd.accepting[fwd.start]) return false;         // (patterns that accept "" take another path)
+    if ((anchored && anchored->ncls != K) || fwd.accepting[fwd.start]) return false;   // (patterns that accept "" take another path)
+    // without the anchored table: a one-state stand-in that accepts nothing - the rows are the forward states, no hit is anchored
+    DfaProgram none;
+    if (!anchored) { none.nstates = 1; none.ncls = K; none.start = 0; none.accepting.assign(1, 0); none.next.assign(K, 0); }
+    const DfaProgram &anch = anchored ? *anchored : none;
     std::map<std::pair<uint32_t, uint32_t>, uint32_t> ids;               // (anchored state, sticky state) -> row
     std::vector<std::pair<uint32_t, uint32_t>> pairs;
     auto intern = [&](uint32_t a, uint32_t f) -> int64_t {

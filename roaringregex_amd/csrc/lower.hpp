@@ -172,7 +172,8 @@ struct SearchLineProgram {
     uint32_t nrows = 0, ncols = 0, start = 0, skip = 0;
     std::vector<uint32_t> table;            // [nrows][ncols]
 };
-bool lower_search_line(const DfaProgram &fwd, const DfaProgram &anchored, uint32_t max_rows, SearchLineProgram &out);
+// anchored == nullptr: the forward table alone (rows = its states + SKIP, no hit carries kSearchAnchored: every match start is walked back to)
+bool lower_search_line(const DfaProgram &fwd, const DfaProgram *anchored, uint32_t max_rows, SearchLineProgram &out);
 
 // Stride-2 form of the line-mode search table (the forward pass of the stripe-wise kernel consumes two bytes per dependent
 // lookup, as the match kernel's stride-2 table does): symbols = the table's columns (byte classes, '\n' last), one column

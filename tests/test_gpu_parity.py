@@ -1527,6 +1527,30 @@ def test_search_with_tables_beyond_the_chunk_kernels_lds():
     assert list(zip(s3.cpu().tolist(), e3.cpu().tolist())) == [m for ln in lines2 for m in rep.search_all(ln)]
 
 
+def test_search_with_the_forward_table_alone():
+    """RRX_OPT_SEARCH_ANCHORED 0 (also what a product table beyond 65534 rows falls back to): no hit knows its start, every match is
+    walked back to - the same answers as with the product table, first match, all matches and the one-call form."""
+    import synth
+    for pattern, kind in ((EMAIL, "email"), (U2, "url")):
+        host = synth.corpus(kind, 11, 8 << 20)
+        corpus = rr.Corpus(torch.from_numpy(host).cuda())
+        r, r0 = rr.RRegex(pattern), rr.RRegex(pattern)
+        r0.set_search_anchored(False)
+        assert int(r0.program(rr.PROGRAM_SEARCH_LINE2)[0]) < int(r.program(rr.PROGRAM_SEARCH_LINE2)[0])     # fewer rows
+        s, e = r.search_corpus(corpus)
+        s0, e0 = r0.search_corpus(corpus)
+        assert torch.equal(s, s0) and torch.equal(e, e0), pattern
+        piece = host[:64 << 10]
+        k = int((piece == 10).sum())
+        ws, we = OracleRegex(pattern).search_lines(piece[:int(np.nonzero(piece == 10)[0][-1]) + 1])
+        assert (s0[:k].cpu().numpy() == ws).all() and (e0[:k].cpu().numpy() == we).all(), pattern
+        f, a, b = r.search_all_fused(corpus)
+        f0, a0, b0 = r0.search_all_fused(corpus)
+        assert torch.equal(f, f0) and torch.equal(a, a0) and torch.equal(b, b0), pattern
+        c1 = r0.search_all(corpus)
+        assert torch.equal(c1[2], a) and torch.equal(c1[3], b), pattern
+
+
 def test_search_all_fused_dense_and_long():
     """rrx_search_all where the staging does not hold a chunk's matches (every byte a match: 16384 per chunk), where a
     line runs over many chunks (its owner counts and places matches far beyond its own bytes), where offsets do not fit

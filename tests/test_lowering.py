@@ -397,6 +397,19 @@ def test_search_tables_find_the_earliest_ending_leftmost_match():
                 for lead in (0, 1):
                     assert line2_rep.search_all(ln, lead) == want, (p[:50], ln, want, "stride-2 line form", lead)
             k += int(c)
+        # the forward table alone (RRX_OPT_SEARCH_ANCHORED 0; what a product beyond the row budget falls back to): no hit is anchored
+        if line2_rep is not None:
+            r0 = rr.RRegex(p)
+            r0.set_search_anchored(False)
+            l0 = SearchLine2Replay(r0.program(rr.PROGRAM_SEARCH_LINE2), rv)
+            assert l0.nrows <= line2_rep.nrows and not ((l0.first >> 24) & 0b0101 & ((l0.first >> 25) & 0b0101)).any(), p
+            for ln, s, e in zip(lines, st, en):
+                assert l0.search(ln, 1) == (int(s), int(e)), (p[:50], ln, "forward table alone")
+            try:
+                r.set_search_anchored(False)
+                raise AssertionError("the option must be refused once the tables are built")
+            except rr.RRegexError:
+                pass
 
 
 # ---------------------------------------------------------------------------------------------------------------------------

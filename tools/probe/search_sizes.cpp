@@ -75,7 +75,7 @@ int main(int argc, char **argv) {
         DfaProgram f, r, anch;
         if (!search_dfas(red, 16384, f, r) || !lower_dfa(red, 16384, anch)) { std::printf("%-10s search DFAs too large\n", pp.first.c_str()); continue; }
         SearchLineProgram s;
-        if (!lower_search_line(f, anch, 16383, s)) { std::printf("%-10s fwd %u rev %u anch %u: no line table\n", pp.first.c_str(), f.nstates, r.nstates, anch.nstates); continue; }
+        if (!lower_search_line(f, &anch, 16383, s)) { std::printf("%-10s fwd %u rev %u anch %u: no line table\n", pp.first.c_str(), f.nstates, r.nstates, anch.nstates); continue; }
         std::vector<uint32_t> block;
         const uint32_t nb = mealy_classes(s, block);
         std::vector<uint32_t> ident(s.nrows);
