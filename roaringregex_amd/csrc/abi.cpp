@@ -87,7 +87,18 @@ void mailbox_release(const Mailbox &m) {
     std::lock_guard<std::mutex> lock(g_mail_mu);
     g_mail[m.device].free_slots.push_back(m.slot);
 }
-struct MailboxGuard { Mailbox m; ~MailboxGuard() { mailbox_release(m); } };
+// Returns the slot when the call leaves - but only once the device can no longer write it: a call that queued the mailing kernel
+// and leaves before its stream has drained waits for the stream here, and a slot whose stream does not drain is never handed out again.
+struct MailboxGuard {
+    Mailbox m;
+    hipStream_t stream = nullptr;
+    bool queued = false;                                // the kernel that writes the slot has been launched on `stream`
+    bool drained = false;                               // ... and the stream has been waited for since
+    ~MailboxGuard() {
+        if (queued && !drained && hipStreamSynchronize(stream) != hipSuccess) { (void)hipGetLastError(); return; }
+        mailbox_release(m);
+    }
+};
 
 int instantiated_width(uint32_t W) { return W <= 4 ? (int)W : W <= 6 ? 6 : W <= 8 ? 8 : W <= 12 ? 12 : 16; }
 
@@ -969,15 +980,19 @@ int rrx_corpus_create_ex(int device, const void *d_bytes, size_t nbytes, uint32_
             const size_t first_stripe = (size_t)g * (c->nstripes / kSampleGroups);
             if (hipMemcpy2DAsync(c->h_sample + (size_t)g * 32 * kSampleBytes, kSampleBytes, c->d_bytes + first_stripe * c->stripe, c->stripe,
                                  kSampleBytes, 32, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) {
-                (void)hipGetLastError(); (void)hipHostFree(c->h_sample); c->h_sample = nullptr; c->sample_lanes = 0;
+                (void)hipGetLastError();
+                (void)hipStreamSynchronize((hipStream_t)stream);      // the copies of the groups before this one may still be writing the buffer
+                (void)hipHostFree(c->h_sample); c->h_sample = nullptr; c->sample_lanes = 0;
                 break;
             }
         }
     }
+    mail.stream = (hipStream_t)stream; mail.queued = true;
     rc = dev::mail_results(c->d_base + c->nstripes, d_flags, nbytes ? c->d_bytes + nbytes - 1 : nullptr, mail.m.dev, stream);
     if (rc) { rrx_corpus_free(c); return hip_fail((hipError_t)rc, "line index launch"); }
     e = hipStreamSynchronize((hipStream_t)stream);
     if (e != hipSuccess) { rrx_corpus_free(c); return hip_fail(e, "line index readback"); }
+    mail.drained = true;
     const uint64_t total = mail.m.host[0];
     const uint32_t flags = (uint32_t)mail.m.host[1];
     const uint8_t last = nbytes ? (uint8_t)mail.m.host[2] : (uint8_t)'\n';
@@ -1131,10 +1146,12 @@ int rrx_match_device(const rrx_regex *re, int device, const void *d_bytes, size_
     if (!e) e = dev::scan_counts(d_counts, d_base, d_base + nstripes + 1, nstripes, stream);
     // (words beyond the caller's bitmap are dropped by the compaction; whether there were any follows from the line count)
     if (!e) e = dev::compact_streams(d_counts, d_base, nstripes, stripe, d_slabs, d_accept_bits, cap_words, stream);
+    mail.stream = st; mail.queued = true;
     if (!e) e = dev::mail_results(d_base + nstripes, nullptr, bytes + nbytes - 1, mail.m.dev, stream);
     if (e) return hip_fail((hipError_t)e, "one-pass launch");
     const hipError_t he = hipStreamSynchronize(st);
     if (he != hipSuccess) return hip_fail(he, "one-pass readback");
+    mail.drained = true;
     *nlines = (size_t)mail.m.host[0] + ((uint8_t)mail.m.host[2] != '\n' ? 1 : 0);
     if ((*nlines + 31) / 32 > cap_words) return fail(RRX_ERR_ARG, "accept bitmap too small for the number of strings");
     return RRX_OK;

@@ -131,6 +131,28 @@ while done < npat:
                     print("MISMATCH items", repr(p), r_.engine_name, label, "mix", mix, "first bad", int(np.nonzero(got != ww)[0][:1].sum()), flush=True)
                     sys.exit(1)
                 checked += 1
+        # every fourth round: the same ragged items TILED until the batch reaches the one-call entry's stripe-wise path (>= 65536
+        # items and >= 8 MiB: item_index_kernel in resolve mode, the predicated fallback, the trim-0 insert) - ADVICE r3
+        if done % 4 == 1 and len(nlpos) >= 8:
+            reps = max(-(-70000 // len(nlpos)), -(-(9 << 20) // len(arr)))
+            if reps * len(arr) <= (96 << 20):
+                big1 = torch.from_numpy(np.tile(arr, reps)).cuda()
+                o1 = np.concatenate([[0], nlpos + 1]).astype(np.int64)
+                boff1 = torch.from_numpy(np.concatenate([[0]] + [o1[1:] + k * len(arr) for k in range(reps)]).astype(np.int64)).cuda()
+                a0 = arr[arr != 10]
+                o0 = np.concatenate([[0], np.cumsum(lens[nz])]).astype(np.int64)
+                big0 = torch.from_numpy(np.tile(a0, reps)).cuda() if len(a0) else None
+                boff0 = torch.from_numpy(np.concatenate([[0]] + [o0[1:] + k * len(a0) for k in range(reps)]).astype(np.int64)).cuda()
+                for r_ in engines[:2]:
+                    for label, (dd, oo, tr, ww) in (("trim 1", (big1, boff1, 1, np.tile(want, reps))), ("trim 0", (big0, boff0, 0, np.tile(want[nz], reps)))):
+                        if dd is None or oo.numel() < 65537 or dd.numel() < (8 << 20):
+                            continue
+                        got = r_.match_extents(dd, oo, trim=tr).cpu().numpy()
+                        if (got != ww).any():
+                            print("MISMATCH tiled items", repr(p), r_.engine_name, label, "mix", mix, "reps", reps, "first bad", int(np.nonzero(got != ww)[0][0]), flush=True)
+                            sys.exit(1)
+                        checked += 1
+                del big1, big0
     # ONE long string (rrx_match_string: chunk maps by convergence on the table engine, chunk relations on the NFA engine)
     # against the oracle: random text, and an accepted line repeated (accepted as a whole by starred patterns)
     if done % 3 == 0:
