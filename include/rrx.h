@@ -93,9 +93,13 @@ int         rrx_set_option(rrx_regex *re, int option, int64_t value);
  * per line: accepted, escaped) and lets the NFA engine decide the escaped lines: the result is exact for ANY text, text that
  * resembles the sample runs at table speed.  Built once per regex: by the first rrx_match_corpus against a corpus of 64 MiB or
  * more, from the corpus' own sample, in a background thread (RRX_OPT_BACKGROUND_ORDER 0: in the caller's) - or here, from `text`
- * (host memory, whole lines; the first line fragment is skipped), in the caller's thread.  RRX_ERR_UNSUPPORTED: the regex is
- * not on the NFA lane engine by AUTO's choice, or no table fits.  rrx_sampled_table: 1 = in use, 2 = being built, 0 = none;
- * *table_states, *open_transitions (entries that lead to ESCAPE) describe it.  Host only.                                  */
+ * (host memory, whole lines; the first line fragment is skipped), in the caller's thread.  A table that more than 2 % of its OWN
+ * sample's lines leave is not installed (every escaped line is read twice: text whose live sets are not few - random a/b lines
+ * under (a|b)*a(a|b){40} - stays on the NFA engine at its full rate).  RRX_ERR_UNSUPPORTED: the regex is not on the NFA lane
+ * engine by AUTO's choice, no table fits, or the sample escapes from it.  rrx_sampled_table: 1 = in use, 2 = being built, 0 = none,
+ * 3 = RETIRED: a launch saw more than 5 % of a corpus' lines escape (every launch leaves its count in pinned host memory, the
+ * next one looks at it without waiting) - the regex is back on the NFA engine for good; *table_states, *open_transitions
+ * (entries that lead to ESCAPE) describe the table.  Host only.                                                            */
 int         rrx_learn_table(rrx_regex *re, const void *text, size_t nbytes);
 int         rrx_sampled_table(const rrx_regex *re, uint32_t *table_states, uint32_t *open_transitions);
 /* *lines = the number of lines the NFA engine had to decide in the regex' LAST sampled-table launch on `device` (synchronous:

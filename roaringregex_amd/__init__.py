@@ -492,6 +492,11 @@ class RRegex:
     def sampled_table_pending(self):
         return _L.rrx_sampled_table(self._h, None, None) == 2
 
+    @property
+    def sampled_table_retired(self):
+        """A corpus escaped from the sampled table (more than 5 % of its lines): the regex is back on the NFA engine."""
+        return _L.rrx_sampled_table(self._h, None, None) == 3
+
     def set_flush_slots(self, slots):
         """rrx_set_option(RRX_OPT_FLUSH_SLOTS): 0 = automatic, or 1 ... 32 slots between two common flushes of the stride-2 kernel."""
         _check(_L.rrx_set_option(self._h, OPT_FLUSH_SLOTS, int(slots)))

@@ -139,6 +139,12 @@ struct rrx_regex {
     mutable SampledTableStats sampled_stats;
     struct SampledOnDevice { void *blob = nullptr; dev::Dfa2Device d; };
     mutable std::map<int, const void *> sampled_counter;   // device -> where the last launch counted its escaped lines (under onepass_mu)
+    // The same count, copied by every sampled launch into pinned host memory behind its kernels.
+    // The NEXT launch looks at it without waiting (it shows the last launch that has finished): a corpus that escapes from the table
+    // - not the text it was learnt from - retires the table (sampled_retired), the regex is back on the NFA engine at its own rate.
+    mutable unsigned long long *h_sampled_seen = nullptr;  // hipHostMalloc (under onepass_mu)
+    mutable unsigned long long sampled_prev_lines = 0;     // lines of the last sampled launch queued (under onepass_mu)
+    mutable std::atomic<bool> sampled_retired{false};
     mutable std::map<int, SampledOnDevice> sampled_on_device;
     bool sampled_eligible() const { return requested_engine == RRX_ENGINE_AUTO && engine == RRX_ENGINE_NFA && !has_dfa && has_nfa; }
     // pieces x piece_bytes of text -> the table; false: nothing usable came out (the engine stays as it is)
@@ -153,6 +159,10 @@ struct rrx_regex {
             ok = d.nstates <= 4096 && lower_dfa2(d, 1024, d2) && (size_t)d2.nstates * (d2.ncols | 1u) * 4 <= dev::kDfa2MaxTable;
         }
         if (!ok || d.escaped.empty()) return false;      // (no escape state: the closure closed the table - lower_dfa would have too)
+        // A table its own sample escapes from is the wrong tool: every escaped line is read a second time by the NFA engine, so
+        // text whose live sets are NOT few (random a/b lines under (a|b)*a(a|b){40}: every line escapes) would run at a fraction of
+        // the plain NFA engine's rate.  More than 2 % of the sample's lines: the engine stays as it is.
+        if (st.sample_escapes * 50 > st.sample_lines) return false;
         std::lock_guard<std::mutex> lock(mu);
         sampled_dfa = std::move(d); sampled_dfa2 = std::move(d2); sampled_stats = st;
         sampled_ready.store(true, std::memory_order_release);
@@ -337,6 +347,7 @@ struct rrx_regex {
         t2_order.wait();
         sampled_build.wait();
         for (auto &kv : sampled_on_device) if (kv.second.blob) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.blob); }
+        if (h_sampled_seen) { (void)hipDeviceSynchronize(); (void)hipHostFree(h_sampled_seen); }      // (a copy into it may still be queued)
         for (auto &kv : t2_extra_blobs) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second); }
         for (auto &kv : scratch) if (kv.second.p) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.p); }
         for (auto &kv : onepass_scratch) {
@@ -818,7 +829,7 @@ int rrx_learn_table(rrx_regex *re, const void *text, size_t nbytes) {
     bool built = false;
     if (!re->sampled_build.start([&]() { built = re->build_sampled(p, 1, (uint32_t)nbytes); }, /*background=*/false))
         return fail(RRX_ERR_ARG, "the sampled table has been decided already");
-    return built ? RRX_OK : fail(RRX_ERR_UNSUPPORTED, "no sampled table fits the device for this automaton and text");
+    return built ? RRX_OK : fail(RRX_ERR_UNSUPPORTED, "no sampled table for this automaton and text: none fits the device, or more than 2 % of the text's own lines leave it");
 }
 int rrx_sampled_table(const rrx_regex *re, uint32_t *table_states, uint32_t *open_transitions) {
     const OnceTask::State st = re->sampled_build.state();
@@ -826,7 +837,7 @@ int rrx_sampled_table(const rrx_regex *re, uint32_t *table_states, uint32_t *ope
     std::lock_guard<std::mutex> lock(re->mu);
     if (table_states) *table_states = ready ? re->sampled_dfa.nstates : 0;
     if (open_transitions) *open_transitions = ready ? re->sampled_stats.open_transitions : 0;
-    return ready ? 1 : st == OnceTask::kRunning ? 2 : 0;
+    return ready ? (re->sampled_retired.load() ? 3 : 1) : st == OnceTask::kRunning ? 2 : 0;
 }
 int rrx_sampled_escapes(const rrx_regex *re, int device, uint64_t *lines) {
     if (!re || !lines) return fail(RRX_ERR_ARG, "null argument");
@@ -1046,11 +1057,22 @@ static int match_corpus_sampled(const rrx_regex *re, const rrx_corpus *c, const 
     unsigned long long *total = reinterpret_cast<unsigned long long *>(static_cast<uint8_t *>(buf) + wide_bytes + esc_bytes);
     uint64_t *list = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(buf) + wide_bytes + esc_bytes + 16);
     re->sampled_counter[c->device] = total;
+    if (!re->h_sampled_seen && hipHostMalloc(reinterpret_cast<void **>(&re->h_sampled_seen), sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess)
+        re->h_sampled_seen[0] = 0;
+    if (re->h_sampled_seen) {
+        // what the last FINISHED launch counted, against the size of the last launch queued (the same corpus in a scan loop; otherwise a hint)
+        const unsigned long long esc_seen = re->h_sampled_seen[0];
+        if (re->sampled_prev_lines >= 1024 && esc_seen * 20 > re->sampled_prev_lines) re->sampled_retired.store(true);   // > 5 % of the lines: the wrong table for this text
+    }
     hipError_t he = hipMemsetAsync(wide, 0, wide_bytes, st);                     // (the kernel merges words with atomic OR)
     if (he == hipSuccess) he = hipMemsetAsync(total, 0, 16, st);
     int e = he != hipSuccess ? (int)he : dev::match_stripes_dfa2_two_bit(d2, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, wide, stream);
     if (!e) e = dev::split_two_bit(wide, c->nlines, d_accept_bits, escaped, total, list, cap, stream);
     if (!e) e = dev::recheck_escaped_nfa(t->nfa, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, escaped, c->nlines, list, total, cap, d_accept_bits, stream);
+    if (!e && re->h_sampled_seen) {                                              // behind the kernels: the count into pinned memory (nobody waits for it)
+        if (hipMemcpyAsync(re->h_sampled_seen, total, sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess) (void)hipGetLastError();
+        re->sampled_prev_lines = c->nlines;
+    }
     const int rc2 = re->onepass_done(c->device, st);
     if (e) return hip_fail((hipError_t)e, "sampled-table launch");
     return rc2;
@@ -1073,7 +1095,7 @@ int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accep
             (void)re->sampled_build.start([re, text, pieces]() { (void)re->build_sampled(text->data(), pieces, kSampleBytes); },
                                           /*background=*/re->opt_background_order.load() != 0);
         }
-        if (re->sampled_ready.load(std::memory_order_acquire)) return match_corpus_sampled(re, c, t, d_accept_bits, stream);
+        if (re->sampled_ready.load(std::memory_order_acquire) && !re->sampled_retired.load()) return match_corpus_sampled(re, c, t, d_accept_bits, stream);
     }
     // the kernel merges words with atomic OR: start from an all-zero bitmap
     HIP_TRY(hipMemsetAsync(d_accept_bits, 0, rrx_corpus_bitmap_words(c) * sizeof(uint32_t), (hipStream_t)stream));

@@ -1061,9 +1061,10 @@ bool lower_dfa_sampled(const Reduced &red, const uint8_t *sample, uint32_t piece
         while (i < piece_bytes && t[i] != '\n') i++;    // a piece begins inside somebody's line: enter at the first line start
         i++;
         uint32_t cur = 1;
+        if (i < piece_bytes) st.sample_lines++;
         for (; i < piece_bytes; i++) {
             const uint8_t c = t[i];
-            if (c == '\n') { cur = 1; continue; }
+            if (c == '\n') { cur = 1; if (i + 1 < piece_bytes) st.sample_lines++; continue; }
             if (cur == kEscape) continue;               // until the end of the line
             st.sample_bytes_stepped++;
             cur = resolve(cur, c < 0x80 ? red.cls[c] : 0);

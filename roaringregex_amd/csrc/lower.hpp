@@ -154,7 +154,7 @@ bool lower_dfa(const Reduced &r, uint32_t max_states, DfaProgram &out);
 // what stays open leads to the ESCAPE state (absorbing until the end of the line, neither accepting nor rejecting: d.escaped).
 // A line that ends outside ESCAPE has exactly the reference's verdict; a line that ends in it must be decided by an exact
 // engine.  Returns false if nothing could be built (an empty automaton; a sample without a line start).
-struct SampledTableStats { uint32_t sets_from_sample = 0, sets_from_closure = 0, open_transitions = 0; uint64_t sample_bytes_stepped = 0, sample_escapes = 0; };
+struct SampledTableStats { uint32_t sets_from_sample = 0, sets_from_closure = 0, open_transitions = 0; uint64_t sample_bytes_stepped = 0, sample_escapes = 0, sample_lines = 0; };   // (sample_escapes: LINES of the sample that left the table as built)
 bool lower_dfa_sampled(const Reduced &r, const uint8_t *sample, uint32_t pieces, uint32_t piece_bytes, uint32_t max_states, DfaProgram &out,
                        SampledTableStats *stats = nullptr);
 

@@ -462,7 +462,9 @@ def test_sampled_table_for_automata_that_do_not_determinise():
         plain.set_sampled_table(False)
         states, open_tr = r.learn_table(url[:1 << 16])
         assert 20 < states < 2000 and open_tr > 0 and r.sampled_table == (states, open_tr)
-        for name, ls, tailnl in (("like the sample", lines[:30000], b"\n"), ("hostile", hostile, b""), ("dirty", dirty, b"\n"), ("mixed", mixed, b"\n")):
+        # (the hostile text last: a launch that sees more than 5 % of the lines escape RETIRES the table - the launches after it run on
+        # the NFA engine, still exact)
+        for name, ls, tailnl in (("like the sample", lines[:30000], b"\n"), ("dirty", dirty, b"\n"), ("mixed", mixed, b"\n"), ("hostile", hostile, b"")):
             data = np.frombuffer(b"\n".join(ls) + tailnl, dtype=np.uint8)
             clean = not (data >= 0x80).any()
             want = o.match_lines(data)
@@ -476,6 +478,11 @@ def test_sampled_table_for_automata_that_do_not_determinise():
                     assert r.sampled_escapes() > 1000, "the hostile text is meant to escape"
                 if name == "like the sample":
                     assert r.sampled_escapes() < len(ls) // 50
+                if name != "hostile":
+                    assert not r.sampled_table_retired, name
+        torch.cuda.synchronize()
+        r.match_corpus_bits(corpus)                                 # (the launch that looks at the hostile launches' count)
+        assert r.sampled_table_retired and r.sampled_table is None
         assert plain.sampled_table is None
     # an automaton that determinises has no use for it; neither has a forced engine
     with pytest.raises(rr.RRegexError):
@@ -510,6 +517,29 @@ def test_sampled_table_learnt_from_the_first_large_corpus():
     assert r.sampled_table is not None, launches
     for _ in range(3):
         assert torch.equal(r.match_corpus_bits(corpus), ref)
+
+
+def test_sampled_table_is_not_installed_where_the_text_escapes_from_it():
+    """(a|b)*a(a|b){40} over random a/b lines: every line reaches a set no sample has shown, a sampled table would send every line
+    through the NFA engine a second time.  The build (started by the first launch against a large corpus) must find that on its own
+    sample and leave the regex on the NFA engine; results are the oracle's before and after."""
+    import synth
+    import time
+    pattern = "(a|b)*a(a|b){40}"
+    data = synth.corpus("ablines", 7, 80 << 20)
+    corpus = rr.Corpus(torch.from_numpy(data).cuda())
+    head = data[:256 << 10]
+    cut = int(np.flatnonzero(head == 10)[-1]) + 1
+    want = OracleRegex(pattern).match_lines(head[:cut])
+    r = rr.RRegex(pattern)
+    assert r.engine == rr.ENGINE_NFA
+    first = r.match_corpus(corpus).cpu().numpy()
+    assert (first[:len(want)] == want).all() and 0 < want.sum() < len(want)
+    t0 = time.time()
+    while r.sampled_table_pending and time.time() - t0 < 60:
+        time.sleep(0.05)
+    assert not r.sampled_table_pending and r.sampled_table is None
+    assert (r.match_corpus(corpus).cpu().numpy() == first).all()
 
 
 def test_table_order_from_a_caller_sample_after_the_tables_are_up():

@@ -585,6 +585,14 @@ def test_sampled_table_decides_exactly_or_not_at_all():
         assert escaped > 50 and decided > 4000
         data = b"\n".join(like[:600] + tails[:80]) + b"\n"
         assert rep.match_lines2(data) == [rep.verdict(ln) for ln in like[:600] + tails[:80]]
+    # a table its OWN sample escapes from is not installed (every escaped line is read twice): (a|b)*a(a|b){40} over random a/b lines
+    # meets a new set on every line
+    ab = np.frombuffer(b"\n".join(bytes(rng.choice(b"ab") for _ in range(rng.randint(60, 120))) for _ in range(600)) + b"\n", dtype=np.uint8)
+    r = rr.RRegex("(a|b)*a(a|b){40}")
+    assert r.engine == rr.ENGINE_NFA
+    with pytest.raises(rr.RRegexError, match="2 %"):
+        r.learn_table(ab)
+    assert r.sampled_table is None and r.program(rr.PROGRAM_SAMPLED_DFA) is None
     # an automaton that determinises has no use for a sampled table; a forced engine is left alone
     with pytest.raises(rr.RRegexError, match="AUTO"):
         rr.RRegex(U2).learn_table(url[:4096])
