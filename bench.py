@@ -352,21 +352,26 @@ def main():
 
     accepted = int(regex.match_corpus(corpus).sum(dtype=torch.int64).item())
     # the same launches on the stride-2 table AS NUMBERED (a second regex that is forbidden the order search), so that the record
-    # carries what the profiled order is worth on this box; rank 0 at N = 1 only, after the timed region
-    numbered_ms = None
+    # carries what the profiled order is worth on this box: two alternating rounds of ten launches each, after the
+    # timed region; rank 0 at N = 1 only
+    order_ab = None
     if rank == 0 and world == 1 and regex.table_order is not None:
         plain = rr.RRegex(pattern, getattr(rr, ENGINES[args.engine]), device=local_rank)
         plain.set_background_order(False)
         for _ in range(3):
             plain.match_corpus_bits(corpus, out=out)
-        ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(args.steps, 10))]
-        for a, b in ev2:
-            a.record()
-            plain.match_corpus_bits(corpus, out=out)
-            b.record()
-        torch.cuda.synchronize()
+        sums = {"ordered": [], "numbered": []}
+        for _ in range(2):
+            for name, r_ in (("ordered", regex), ("numbered", plain)):
+                ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+                for a, b in ev2:
+                    a.record()
+                    r_.match_corpus_bits(corpus, out=out)
+                    b.record()
+                torch.cuda.synchronize()
+                sums[name] += [a.elapsed_time(b) for a, b in ev2]
         assert plain.table_order is None
-        numbered_ms = round(sum(a.elapsed_time(b) for a, b in ev2) / len(ev2), 4)
+        order_ab = {k: round(sum(v) / len(v), 4) for k, v in sums.items()}
         del plain
     if rank == 0:
         avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
@@ -390,7 +395,7 @@ def main():
                                    % (config_name, regex.states_n, "BitSet<%d>" % regex.set_class if regex.set_class else "Roaring", nbytes / 2**30),
                        "pattern_states": regex.states_n, "useful_states": regex.useful_states, "engine": regex.engine_name,
                        "table_order_profiled_conflicts_before_after": regex.table_order, "table_order_wait_ms": round(order_wait_ms, 1),
-                       "kernel_ms_avg_table_as_numbered": numbered_ms,
+                       "table_order_ab_kernel_ms": order_ab,
                        "sampled_table_states_open_transitions": regex.sampled_table,
                        "sampled_table_escaped_lines_last_launch": regex.sampled_escapes() if regex.sampled_table else None,
                        "bytes_per_gpu": nbytes, "stripe_bytes": corpus.stripe, "lines_per_gpu": nlines, "accepted_rank0": accepted, "sharding": sharding},
