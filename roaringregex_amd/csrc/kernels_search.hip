@@ -410,20 +410,6 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     const uint8_t *const cbase = bytes + cstart;
     auto text_word = [&](uint32_t at) -> uint32_t { return *reinterpret_cast<const uint32_t *>(cbase + at); };   // at: multiple of 4
     uint32_t fill = 0;                                            // jobs in the pool (wave-uniform; the pool is empty between chunks and passes)
-    // (r4) ARMED: as soon as the pool holds 64 jobs the two text words each of them starts from are REQUESTED (arm(), called at the next
-    // reservation: the pool then holds everything pushed before) and kept in two registers per lane; the walk comes when the pool runs
-    // over, some event words later, and finds them there.  A round of walks used to begin with that round trip to L2 in the open -
-    // six rounds per 16-KiB chunk on the email config.  Slots 0 .. 63 do not change between arm() and the walk (pushes go behind them).
-    bool armed = false;                                           // wave-uniform
-    uint32_t armed_hi = 0, armed_lo = 0;
-    auto arm = [&]() {
-        const uint32_t e_rel = pool[4 * lane + 1];
-        const uint32_t a1 = e_rel & ~3u;
-        armed_hi = 0; armed_lo = 0;
-        if (e_rel & 3u) armed_hi = text_word(a1);
-        if (a1 >= 4u) armed_lo = text_word(a1 - 4u);
-        armed = true;
-    };
     // everything: every job in the pool; otherwise whole rounds of 64 only (the rest moves to the front and waits for company)
     auto drain = [&](bool everything) {
         const uint32_t count = fill;
@@ -431,7 +417,6 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
         while (everything ? base < count : base + 64u <= count) {
             const uint32_t jn = base + (uint32_t)lane;
             const bool have = jn < count;
-            const bool preloaded = armed && base == 0u;           // (armed: the pool held 64 jobs then, so every lane has one)
             base += 64u;
             uint32_t lo = 0, e_rel = 0, cur_at = 0, cur_ls = 0, kb = 0, best = 0, r = 0, hi_w = 0, lo_w = 0, sh = 0;
             if (have) {
@@ -439,11 +424,8 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
                 kb = e_rel; best = e_rel; r = t.start_row;      // e_rel > lo: a match is never empty here
                 sh = kb & 3u;
                 const uint32_t a1 = kb & ~3u;                     // the word that holds byte kb: its low `sh` bytes are wanted
-                if (preloaded) { hi_w = armed_hi; lo_w = armed_lo; }
-                else {
-                    if (sh) hi_w = text_word(a1);
-                    if (a1 >= 4u) lo_w = text_word(a1 - 4u);      // (a1 < 4: sh > 0 and lo = 0 - the wanted bytes are all in hi_w)
-                }
+                if (sh) hi_w = text_word(a1);
+                if (a1 >= 4u) lo_w = text_word(a1 - 4u);          // (a1 < 4: sh > 0 and lo = 0 - the wanted bytes are all in hi_w)
             }
             bool active = have;
             while (__ballot(active)) {
@@ -478,13 +460,11 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
             pool[4 * lane] = v0; pool[4 * lane + 1] = v1; pool[4 * lane + 2] = v2; pool[4 * lane + 3] = v3;
         }
         fill = (uint32_t)__builtin_amdgcn_readfirstlane((int)rem);
-        armed = false;
     };
     // Wave-uniform, before a turn in which the lanes push n jobs between them (exactly n: every reserved slot gets its job,
     // the pool has no holes): -> the first of their slots; slots >= kPool do not exist, those lanes walk alone.  The lanes
     // take consecutive slots in lane order (lane_offset: jobs of the lanes below me, from per-lane counts of 0 .. 4).
     auto reserve = [&](uint32_t n) -> uint32_t {
-        if (!armed && fill >= 64u) arm();
         if (fill + n > kPool) { drain(false); if (fill + n > kPool) drain(true); }
         const uint32_t first_slot = fill;
         fill = (uint32_t)__builtin_amdgcn_readfirstlane((int)(fill + n < kPool ? fill + n : kPool));      // (wave-uniform: keep it in a scalar register)
