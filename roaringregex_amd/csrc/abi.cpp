@@ -560,32 +560,51 @@ struct rrx_regex {
                 if (nfa_block.excm[w]) t.block.exc_words |= 1u << (w % WL);
             }
         } else if (engine == RRX_ENGINE_NFA_WAVE) {
-            // group-cooperative form: G lanes x 64 positions; a B row per byte value
+            // group-cooperative form: G lanes x K words (device.hpp: group_geometry), a B row per byte CLASS
             const uint32_t W = nfa_wave.W, N = nfa_wave.nbits;
-            const uint32_t G = N <= 1024 ? 16 : 32, WP = 2 * G;
-            std::vector<uint32_t> M((size_t)3 * WP, 0), B((size_t)256 * WP, 0);
+            uint32_t G = 0, K = 0;
+            if (!dev::group_geometry(N, &G, &K)) return fail(RRX_ERR_UNSUPPORTED, "automaton too large for the group-cooperative engine");
+            const uint32_t WP = G * K, NC = trimmed.ncls;
+            std::vector<uint32_t> M((size_t)3 * WP, 0), B((size_t)NC * WP, 0);
             const std::vector<uint32_t> *src[3] = {&nfa_wave.fin, &nfa_wave.self, &nfa_wave.excm};
             for (int k = 0; k < 3; k++) for (uint32_t w = 0; w < W; w++) M[(size_t)k * WP + w] = (*src[k])[w];
-            for (uint32_t c = 1; c < 128; c++)                            // 0x00 and >= 0x80: empty rows
-                for (uint32_t w = 0; w < W; w++) B[(size_t)c * WP + w] = nfa_wave.B[(size_t)c * W + w];
+            for (uint32_t cl = 1; cl < NC; cl++) {                        // class 0 (0x00, >= 0x80, bytes nothing moves on): empty row
+                const uint32_t c = trimmed.cls_rep[cl];
+                for (uint32_t w = 0; w < W; w++) B[(size_t)cl * WP + w] = nfa_wave.B[(size_t)c * W + w];
+            }
+            uint8_t cmap[256];
+            for (int c = 0; c < 256; c++) cmap[c] = (c == 0 || c >= 128) ? 0 : trimmed.cls[c];
+            // slots (word index within a lane) that carry masks at all: a slot whose B rows are all ones on every POSITION IN USE for
+            // every class >= 1 needs no AND (positions beyond nbits are never set: their row bits do not matter)
+            uint32_t self_slots = 0, b_slots = 0, exc_slots = 0;
+            for (uint32_t w = 0; w < WP; w++) {
+                const uint32_t used = w * 32 >= N ? 0u : (N - w * 32 >= 32 ? 0xffffffffu : (1u << (N - w * 32)) - 1u);
+                if (w < W && nfa_wave.self[w]) self_slots |= 1u << (w % K);
+                if (w < W && nfa_wave.excm[w]) exc_slots |= 1u << (w % K);
+                for (uint32_t cl = 1; cl < NC; cl++)
+                    if ((B[(size_t)cl * WP + w] & used) != used) b_slots |= 1u << (w % K);
+            }
             std::vector<uint16_t> xidx(N, 0xffff);
             std::vector<uint32_t> X;
             uint32_t rows = 0;
-            bool front = true;
             for (uint32_t b = 0; b < N; b++) {
                 if (!((nfa_wave.excm[b >> 5] >> (b & 31)) & 1u)) continue;
-                if (b >= 32) front = false;
                 xidx[b] = (uint16_t)rows++;
                 X.resize((size_t)rows * WP, 0);
-                for (uint32_t w = 0; w < W; w++) X[(size_t)(rows - 1) * WP + w] = nfa_wave.X[(size_t)b * W + w];
+                for (uint32_t i = nfa_wave.xoff[b]; i < nfa_wave.xoff[b + 1]; i++) {      // (the CSR lists exist at every size, dense rows only up to 4096 positions)
+                    const uint32_t tv = nfa_wave.xtgt[i];
+                    X[(size_t)(rows - 1) * WP + (tv >> 5)] |= 1u << (tv & 31);
+                }
             }
             if (X.empty()) X.assign(WP, 0);
             oM = put(M.data(), M.size() * 4);
             oB = put(B.data(), B.size() * 4);
             oX = put(X.data(), X.size() * 4);
             oXI = put(xidx.data(), xidx.size() * 2);
-            t.group.G = G; t.group.nbits = N; t.group.n_exc = rows;
-            t.group.exc_mode = (rows == 1 && xidx[0] == 0) ? 2 : front ? 1 : 0;
+            oCP = put(cmap, 256);
+            t.group.G = G; t.group.K = K; t.group.nbits = N; t.group.n_exc = rows; t.group.ncls = NC;
+            t.group.self_slots = self_slots; t.group.b_slots = b_slots; t.group.exc_slots = exc_slots;
+            t.group.exc_mode = (rows == 1 && xidx[0] == 0) ? 2 : 0;
         } else if (engine == RRX_ENGINE_NFA) {
             const uint32_t W = nfa.W, WP = (uint32_t)instantiated_width(W);
             std::vector<uint32_t> B((size_t)256 * WP, 0), X((size_t)nfa.nbits * WP, 0);
@@ -669,7 +688,8 @@ struct rrx_regex {
             t.block.xtgt = reinterpret_cast<const uint32_t *>(base + oXT);
         } else if (engine == RRX_ENGINE_NFA_WAVE) {
             t.group.masks = reinterpret_cast<const uint32_t *>(base + oM);
-            t.group.Bbyte = reinterpret_cast<const uint32_t *>(base + oB);
+            t.group.Bcls = reinterpret_cast<const uint32_t *>(base + oB);
+            t.group.cls = base + oCP;
             t.group.X = reinterpret_cast<const uint32_t *>(base + oX);
             t.group.xidx = reinterpret_cast<const uint16_t *>(base + oXI);
         } else if (engine == RRX_ENGINE_NFA) {

@@ -53,18 +53,31 @@ struct NfaDevice {                               // tables in HBM (copied to LDS
     const uint32_t *X = nullptr;                 // [nbits][W]
 };
 
-// Group-cooperative NFA (automata beyond kMaxNfaWords*32 positions): the state set is spread over G = 16 or 32 neighbouring
-// lanes of a wave, one 64-bit word per lane (1024 / 2048 positions); a wave steps 64 / G strings.
-constexpr uint32_t kGroupMaxBits = 2048;
+// Group-cooperative NFA (automata beyond kMaxNfaWords*32 positions): the state set is spread over G = 8, 16 or 32 neighbouring
+// lanes of a wave, K = 2 ... 8 consecutive 32-bit words per lane (word w of the set: lane w / K of the group, slot w % K), up to
+// 8192 positions; a wave steps 64 / G strings.  (r4: K was fixed at 2 and a string of 2049+ positions took a whole wave.)
+constexpr uint32_t kGroupMaxBits = 8192;
 struct GroupNfaDevice {
-    uint32_t G = 0, nbits = 0, n_exc = 0;
-    uint32_t exc_mode = 0;                       // 0: exception positions anywhere; 1: only in word 0 of the group's lane 0;
-                                                 //   2: position 0 (live on the first byte of a line only) is the only one
-    const uint32_t *masks = nullptr;             // [3][G][2]: fin, self, excm
-    const uint32_t *Bbyte = nullptr;             // [256][G][2]: positions enterable on a byte value (0x00 and >= 0x80: none)
+    uint32_t G = 0, K = 0, nbits = 0, n_exc = 0, ncls = 0;
+    uint32_t exc_mode = 0;                       // 0: exception positions anywhere; 2: position 0 (live on the first byte of a line
+                                                 //   only) is the only one
+    uint32_t self_slots = 0;                     // bit k: slot k of some lane holds a self loop
+    uint32_t b_slots = 0;                        // bit k: slot k of some lane has a B row that is not all ones for some class >= 1
+                                                 //   (the other slots are stepped by the shift alone; a class-0 byte kills the line)
+    uint32_t exc_slots = 0;                      // bit k: slot k of some lane holds an exception position
+    const uint32_t *masks = nullptr;             // [3][G][K]: fin, self, excm
+    const uint32_t *Bcls = nullptr;              // [ncls][G][K]: positions enterable on a byte class (class 0: none)
+    const uint8_t *cls = nullptr;                // [256] byte -> class (0x00 and >= 0x80: class 0)
     const uint16_t *xidx = nullptr;              // [nbits] exception row of a position (0xffff: none)
-    const uint32_t *X = nullptr;                 // [n_exc][G][2]
+    const uint32_t *X = nullptr;                 // [n_exc][G][K]
 };
+// the geometry for `nbits` positions: the fewest lanes whose words hold them (more strings per wave), false beyond kGroupMaxBits
+inline bool group_geometry(uint32_t nbits, uint32_t *G, uint32_t *K) {
+    static const uint32_t forms[][2] = {{8, 3}, {8, 4}, {16, 3}, {16, 4}, {32, 3}, {32, 4}, {32, 5}, {32, 8}};
+    for (const auto &f : forms)
+        if (nbits <= f[0] * f[1] * 32u) { *G = f[0]; *K = f[1]; return true; }
+    return false;
+}
 
 // Wave-resident NFA (automata beyond kGroupMaxBits positions, kernels_wave.hip): ONE WAVE holds one state set, WL 32-bit
 // words per lane (WL = 1 ... 32: up to 65536 positions); exception edges are CSR lists, not rows.

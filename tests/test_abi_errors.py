@@ -36,9 +36,10 @@ def test_oversized_automata_are_refused_quickly():
     with pytest.raises(rr.RRegexError, match="too many states"):
         rr.RRegex("(a|b)*a(a|b){20000}")
     assert time.time() - t0 < 20
-    # > 4096 positions and an exploding subset construction: only the wave-resident engine admits it
+    # > 8192 positions and an exploding subset construction: only the wave-resident engine admits it (the group engine: 32 lanes x 8 words)
+    assert rr.RRegex("(a|b)*a(a|b){5000}", rr.ENGINE_NFA_WAVE).engine_name == "nfa-group-cooperative"
     with pytest.raises(rr.RRegexError, match="too large"):
-        rr.RRegex("(a|b)*a(a|b){5000}", rr.ENGINE_NFA_WAVE)
+        rr.RRegex("(a|b)*a(a|b){8200}", rr.ENGINE_NFA_WAVE)
     # forcing an engine that cannot hold the automaton is refused as well
     with pytest.raises(rr.RRegexError, match="too large"):
         rr.RRegex("(a|b)*a(a|b){600}", rr.ENGINE_NFA)

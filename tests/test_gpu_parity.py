@@ -738,16 +738,47 @@ def _coop_engine_case(pattern, engine, engine_name, lengths, seed, alphabet="ab"
 
 
 def test_group_engine_32_lanes_per_string_and_beyond():
-    """match_stripes_group_kernel<32> (1025-2048 positions: two strings per wave, wave_shr:1 carries a word across a DPP
-    row boundary), with its extents form; beyond 2048 positions a string takes a whole wave (the wave-resident engine).
+    """match_stripes_group_kernel<G, K, ...>: G lanes x K words per string (r4; K was 2).  16 x 3 words (1025-1536 positions: row_shr:1
+    inside a DPP row), 32 x 3 / 32 x 5 / 32 x 8 (two strings per wave, wave_shr:1 carries a word across a DPP row boundary; up to 8192
+    positions), with their extents forms; beyond 8192 positions a string takes a whole wave (the wave-resident engine).  These
+    patterns are the slot-0 build (only word 0 of a lane carries masks); the general build: the third case and the a{1,n} family.
     Reference: any automaton size, Parser.cpp:165; the loop, NFA.cc:77-85."""
     _coop_engine_case("(a|b)*a(a|b){1500}", rr.ENGINE_AUTO, "nfa-group-cooperative", (0, 1, 1500, 1501, 1502, 1503, 1600, 2100, 3300, 5000), 31)
     assert rr.RRegex("(a|b)*a(a|b){1500}").words_per_set == 47
-    _coop_engine_case("(a|b)*a(a|b){3000}", rr.ENGINE_AUTO, "nfa-wave-resident", (0, 2, 3000, 3001, 3002, 3003, 3100, 4200, 6100, 9000), 32)
+    _coop_engine_case("(a|b)*a(a|b){3000}", rr.ENGINE_AUTO, "nfa-group-cooperative", (0, 2, 3000, 3001, 3002, 3003, 3100, 4200, 6100, 9000), 32)
     assert rr.RRegex("(a|b)*a(a|b){3000}").words_per_set == 94
+    _coop_engine_case("(a|b)*a(a|b){5000}", rr.ENGINE_AUTO, "nfa-group-cooperative", (0, 2, 5000, 5001, 5002, 5003, 5100, 7000, 10100), 35,
+                      stripes=(1024, 16384), facade=2, boundary_lines=6)
+    _coop_engine_case("(a|b)*a(a|b){8100}", rr.ENGINE_AUTO, "nfa-group-cooperative", (0, 2, 8100, 8101, 8102, 8103, 8200, 16300), 36,
+                      stripes=(1024, 16384), facade=2, boundary_lines=4)
+    _coop_engine_case("(a|b)*a(a|b){8200}", rr.ENGINE_AUTO, "nfa-wave-resident", (0, 2, 8200, 8201, 8202, 8203, 8300, 16500), 37,
+                      stripes=(1024, 16384), per_length=1, facade=2, boundary_lines=4)
+    # a text byte outside the pattern's classes in the slot-0 build: the slots without masks cannot be cleared - the line is dead by flag
+    _coop_engine_case("(a|b)*a(a|b){1500}", rr.ENGINE_AUTO, "nfa-group-cooperative", (1, 1502, 1503, 1600, 3300), 38, alphabet="abc", stripes=(1024, 16384))
     # exception edges reaching across lanes and rows of the group (not just the add-one chain)
     _coop_engine_case("((a|b)*a(a|b){700}c|(b|c)*b(b|c){800}a)*", rr.ENGINE_NFA_WAVE, "nfa-group-cooperative",
                       (0, 3, 702, 703, 802, 803, 1505, 1506, 2207, 2400), 33, alphabet="abc", stripes=(1024, 16384), facade=2)
+
+
+def test_group_engine_runs_through_several_stripes_per_group():
+    """On a corpus large enough the group kernel gives a group SEVERAL consecutive stripes of the index (span > 1: the stripe is
+    chosen for lane-per-stripe engines): 256 MiB of 500-900-byte a/b lines at 1 KiB stripes - (a|b)*a(a|b){600} on 8 lanes x 3 words
+    (span 2) and (a|b)*a(a|b){5000} on 32 lanes x 5 words (span 8) - bit for bit the wave-resident engine's result, the oracle's on
+    the first lines."""
+    import synth
+    data = synth.corpus("ablong", 29, 256 << 20)
+    dev = torch.from_numpy(data).cuda()
+    corpus = rr.Corpus(dev, stripe=1024)
+    head = data[:192 << 10]
+    cut = int(np.flatnonzero(head == 10)[-1]) + 1
+    for pattern in ("(a|b)*a(a|b){600}", "(a|b)*a(a|b){5000}"):
+        r = rr.RRegex(pattern)
+        assert r.engine_name == "nfa-group-cooperative"
+        got = r.match_corpus_bits(corpus).clone()
+        ref = rr.RRegex(pattern, rr.ENGINE_NFA_BLOCK).match_corpus_bits(corpus)
+        assert torch.equal(got, ref), pattern
+        want = OracleRegex(pattern).match_lines(head[:cut])
+        assert (r.match_corpus(corpus).cpu().numpy()[:len(want)] == want).all(), pattern
 
 
 def test_block_engine_512_lanes():
@@ -919,15 +950,15 @@ def test_one_shot_entry_reads_the_text_once_and_agrees_with_the_indexed_path():
 
 
 def test_block_cooperative_engine_beyond_4096_positions():
-    """An automaton with more than 4096 positions (5003: no table form exists, beyond the group engine) compiles to the
+    """An automaton with more than 8192 positions (9003: no table form exists, beyond the group engine) compiles to the
     wave-resident engine and matches the oracle: batch kernel, extents kernel, iterator facade."""
     rng = random.Random(78)
-    p = "(a|b)*a(a|b){5000}"
+    p = "(a|b)*a(a|b){9000}"
     r = rr.RRegex(p)
     assert r.engine_name == "nfa-wave-resident"
     o = OracleRegex(p)
-    lines = ["", "a", "a" + "b" * 5000, "b" + "b" * 5000, "ab" * 100 + "a" + "a" * 5000, "a" * 4999, "a" * 5002]
-    for n in (5001, 5002, 5600, 9000):
+    lines = ["", "a", "a" + "b" * 9000, "b" + "b" * 9000, "ab" * 100 + "a" + "a" * 9000, "a" * 8999, "a" * 9002]
+    for n in (9001, 9002, 9600, 14000):
         lines.append("".join(rng.choice("ab") for _ in range(n)))
     data = ("\n".join(lines)).encode()
     want = o.match_lines(np.frombuffer(data, dtype=np.uint8))

@@ -119,13 +119,14 @@ def test_programs_keep_the_language_random():
 
 
 def test_block_program_beyond_4096_positions():
-    """(a|b)*a(a|b){5000}: 5003 positions, no table form, beyond the group engine -> nfa-wave-resident (the reference's
-    Roaring class at any size, Parser.cpp:165).  Its program (exception edges as CSR lists) replays to the oracle's
+    """(a|b)*a(a|b){5000}: 5003 positions, no table form -> the group engine (r4: up to 8192 positions, 32 lanes x 5 words); forced
+    onto the wave-resident engine here, which AUTO takes beyond that (the reference's Roaring class at any size, Parser.cpp:165).  Its program (exception edges as CSR lists) replays to the oracle's
     answers, in the plain and in the line-mode form; small automata forced onto the engine do too."""
     import numpy as np
     rng = random.Random(43)
     p = "(a|b)*a(a|b){5000}"
-    r = rr.RRegex(p)
+    assert rr.RRegex(p).engine_name == "nfa-group-cooperative" and rr.RRegex("(a|b)*a(a|b){8200}").engine_name == "nfa-wave-resident"
+    r = rr.RRegex(p, rr.ENGINE_NFA_BLOCK)
     assert r.engine == rr.ENGINE_NFA_BLOCK and r.engine_name == "nfa-wave-resident"
     w = r.program(rr.ENGINE_NFA_BLOCK)
     assert w[1] > 4096
