@@ -28,7 +28,7 @@ enum { RRX_OK = 0, RRX_ERR_PATTERN = 1, RRX_ERR_ARG = 2, RRX_ERR_HIP = 3, RRX_ER
 
 /* engine selection for rrx_compile_ex */
 enum { RRX_ENGINE_AUTO = 0, RRX_ENGINE_NFA = 1, RRX_ENGINE_DFA = 2, RRX_ENGINE_DFA_GLOBAL = 3 /* table kept in HBM/L2 */,
-       RRX_ENGINE_NFA_WAVE = 4 /* state set spread over 16 or 32 lanes of a wave: up to 2048 positions */,
+       RRX_ENGINE_NFA_WAVE = 4 /* state set spread over 8, 16 or 32 lanes of a wave, 2-8 words per lane: up to 8192 positions */,
        RRX_ENGINE_DFA2 = 5 /* table with one dependent lookup per two bytes (AUTO prefers it when it fits) */,
        RRX_ENGINE_NFA_BLOCK = 8 /* wave-resident NFA: one wave holds one state set of up to 65536 positions (32 words per lane),
                                    exception edges as sparse lists (the reference's Roaring class, Parser.cpp:165, at any
