@@ -347,7 +347,10 @@ struct rrx_regex {
         t2_order.wait();
         sampled_build.wait();
         for (auto &kv : sampled_on_device) if (kv.second.blob) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.blob); }
-        if (h_sampled_seen) { (void)hipDeviceSynchronize(); (void)hipHostFree(h_sampled_seen); }      // (a copy into it may still be queued)
+        if (h_sampled_seen) {                            // (a copy into it may still be queued on the devices that ran the sampled table)
+            for (auto &kv : sampled_on_device) { (void)hipSetDevice(kv.first); (void)hipDeviceSynchronize(); }
+            (void)hipHostFree(h_sampled_seen);
+        }
         for (auto &kv : t2_extra_blobs) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second); }
         for (auto &kv : scratch) if (kv.second.p) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.p); }
         for (auto &kv : onepass_scratch) {
