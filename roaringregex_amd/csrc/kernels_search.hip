@@ -336,7 +336,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     auto emit = [&](uint32_t idx, uint32_t v0, uint32_t v1) {
         const bool staged = idx < kStageLines;
         if (MODE == kCount) { if (staged) st_s[idx] = v0; else match_start[base_line + idx] = v0; return; }
-        const bool fits = v0 == kNone || v1 < 0xffffu;            // (v0 <= v1)
+        const bool fits = v0 == kNone || v1 < (MODE == kFirst ? 0x8000u : 0xffffu);      // (v0 <= v1; kFirst: bit 31 of a staged entry marks a PARKED hit)
         if (staged) st_s[idx] = v0 == kNone ? kNone : fits ? (v0 | v1 << 16) : kDirect;
         if (!staged || !fits) {
             const uint64_t at = ((MODE == kFill || MODE == kAll) ? F0 : base_line) + idx;
@@ -364,6 +364,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     e = e_fwd; ord = ord0; emitted = 0;
     bool owned = fresh, decided = false;                          // the current line: is it mine; kFirst: has its match been found
     bool fast_count_pass = false;                                 // kCount: the hits added themselves to their lines' staged counts
+    bool parked = false;                                          // kFirst: the hits of my bytes are parked in the staging array (wave-uniform)
     if constexpr (MODE == kAll && !COUNTING) { if (fresh) set_first(ord0, lane_base); }
     const uint32_t my_rel = (uint32_t)(my - cstart), my_end_rel = (uint32_t)(my_end - cstart);
     uint32_t ls = my_rel;                                         // its first byte (valid if owned)
@@ -526,30 +527,32 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
         // ordinal and first byte - are a popcount and a find-first over the '\n' fields in front of it.  (Round 2 took every
         // event in turn, '\n' and hit alike, each a pass through the whole body: on 20-byte lines the event loop cost twice the
         // forward pass; on 5-byte lines three quarters of the events are '\n'.)
+        // (r4) A hit is only PARKED here - at its line's ordinal in the staging array: bit 31 | anchored << 30 | line start << 16 |
+        // match end relative to the line start (both inside the chunk: 14 and 15 bits) - by its own lane in its own loop: no ballot, no
+        // reservation, no walk job.  The lines are then taken 64 at a time, a line per lane (parked_lines, behind the follow loop):
+        // an anchored hit becomes its result, the others are pooled for the walk with every lane of the wave in the game.  (The
+        // round-3 loop took a hit of every lane per turn of a wave-wide loop and did all of that inside it: 0.20 of the email
+        // config's 0.64 ms per GiB, 0.67 of the URL config's 3.2 ms per 8 GiB with the write-out.)
         uint32_t run_ord = ord0, run_ls = my_rel, last_hit_end = 0;
 #pragma unroll
         for (int i = 0; i < kEv; i++) {
             const uint32_t evw = ev[i];
             const uint32_t nlm = evw & ~(evw >> 1) & 0x55555555u;     // fields equal to 1: bit 30 - 2 y for byte y
             uint32_t hm = evw & 0xaaaaaaaau;                          // fields 2 and 3: bit 31 - 2 y
-            while (__ballot(hm != 0)) {
-                uint32_t f = 0, pos = 0;
-                if (hm) {
-                    const int zb = __clz((int)hm);                    // 2 y
-                    hm &= ~(0x80000000u >> zb);
-                    f = (evw >> (30 - zb)) & 3u;
-                    const uint32_t above = zb ? nlm & ~(0xffffffffu >> zb) : 0u;      // the '\n' of this word in front of the hit
-                    pos = my_rel + (uint32_t)(16 * i) + (uint32_t)(zb >> 1);
-                    ord = run_ord + (uint32_t)__popc(above);
-                    ls = above ? my_rel + (uint32_t)(16 * i) + ((uint32_t)(31 - __ffs((int)above)) >> 1) + 1u : run_ls;
-                    owned = true;
-                    last_hit_end = pos + 1u;
-                }
-                reserve_one(f == 2u);
-                if (f) on_hit(pos, f);
+            while (hm) {
+                const int zb = __clz((int)hm);                        // 2 y
+                hm &= ~(0x80000000u >> zb);
+                const uint32_t anchored = (evw >> (30 - zb)) & 1u;
+                const uint32_t above = zb ? nlm & ~(0xffffffffu >> zb) : 0u;          // the '\n' of this word in front of the hit
+                const uint32_t pos = my_rel + (uint32_t)(16 * i) + (uint32_t)(zb >> 1);
+                const uint32_t o = run_ord + (uint32_t)__popc(above);
+                const uint32_t l = above ? my_rel + (uint32_t)(16 * i) + ((uint32_t)(31 - __ffs((int)above)) >> 1) + 1u : run_ls;
+                last_hit_end = pos + 1u;
+                st_s[o] = 0x80000000u | anchored << 30 | l << 16 | (pos + 1u - l);
             }
             if (nlm) { run_ord += (uint32_t)__popc(nlm); run_ls = my_rel + (uint32_t)(16 * i) + ((uint32_t)(31 - __ffs((int)nlm)) >> 1) + 1u; }
         }
+        parked = true;
         ord = run_ord; ls = run_ls; lb = run_ls; cnt = 0;
         owned = nl ? run_ls < my_end_rel : fresh;                     // a line that starts at my_end is the next lane's
         decided = last_hit_end > run_ls;                              // my open last line has its match already
@@ -703,6 +706,28 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
                 uint32_t acc = 0, wrel = 0;
                 follow_step(acc, wrel);
                 follow_events(acc, wrel);
+            }
+        }
+        // ---- 4b'. kFirst: the parked hits, a LINE per lane
+        if constexpr (MODE == kFirst) {
+            if (parked) {
+                for (int64_t j0 = (int64_t)lo_ord; j0 <= hi_ord; j0 += 64) {          // (wave-uniform; every ordinal of the chunk is staged here)
+                    const int64_t j = j0 + lane;
+                    const uint32_t v = j <= hi_ord ? st_s[j] : kNone;
+                    const bool is_parked = v != kNone && v != kDirect && (v >> 31) != 0u;
+                    const uint32_t l = (v >> 16) & 0x3fffu, endrel = v & 0xffffu;
+                    const bool push = is_parked && !((v >> 30) & 1u);
+                    if (is_parked && !push) st_s[j] = endrel << 16;                   // anchored: the match is [0, endrel) of its line
+                    reserve_one(push);
+                    if (push) {
+                        const uint32_t idx = next_slot;
+                        if (idx < kPool) { pool[4 * idx] = l; pool[4 * idx + 1] = l + endrel; pool[4 * idx + 2] = (uint32_t)j; pool[4 * idx + 3] = l; }
+                        else {                                                        // (no room even after a drain)
+                            const size_t s0 = reverse_walk(t, bytes, cstart + l, cstart + l + endrel);
+                            emit((uint32_t)j, (uint32_t)(s0 - cstart) - l, endrel);
+                        }
+                    }
+                }
             }
         }
         // ---- 4c. the walks still waiting
