@@ -123,7 +123,7 @@ def cpu_baseline(pattern, host, target_seconds=12.0):
     """The oracle (CPU port of the reference's loop, NFA.cc:86-100) on a bounded sample of the same corpus,
     one oracle instance per thread (the reference is not re-entrant either), all host cores."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    from pyoracle import OracleRegex
+    from pyoracle import OracleRegex, simd
     cores = host_cores()
     chunk = 1 << 20                                    # corpus chunks end with '\n': line-aligned slices
     # calibrate on 4 MiB, then size the sample for ~target_seconds
@@ -147,7 +147,8 @@ def cpu_baseline(pattern, host, target_seconds=12.0):
     dt = time.perf_counter() - t0
     total = per_thread * cores
     return {"value": round(total / dt / 1e9, 4), "unit": "GB/s", "cores": cores, "kind": "port",
-            "sample": "first %d MiB of the same corpus, %d threads x %d MiB, oracle/rr_oracle.c (-O2)" % (total >> 20, cores, per_thread >> 20),
+            "sample": "first %d MiB of the same corpus, %d threads x %d MiB, oracle/rr_oracle.c (-O2; BitSet<2>/<4> step with %s)"
+                      % (total >> 20, cores, per_thread >> 20, "the reference's vector ORs, SSE2 / AVX2 (BitSet.cc:8-21)" if simd() else "scalar words"),
             "single_core_GBs": round(per_core / 1e9, 4)}
 
 

@@ -58,8 +58,19 @@ def lib():
         L.rro_search_all.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
         L.rro_search_lines.restype = C.c_size_t
         L.rro_search_lines.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t]
+        L.rro_set_simd.argtypes = [C.c_int]
+        L.rro_simd.restype = C.c_int
         _LIB = L
     return _LIB
+
+
+def set_simd(on):
+    """The BitSet<2> / BitSet<4> step with the reference's vector ORs (BitSet.cc:8-21) or with scalar words; same results."""
+    lib().rro_set_simd(1 if on else 0)
+
+
+def simd():
+    return bool(lib().rro_simd())
 
 
 def ref_bitset_lib():

@@ -516,6 +516,56 @@ static int accepts_wn(const rro_nfa *n, const uint8_t *s, size_t len) {
     }
     return rro_bs_and_cardinality(W, cur, n->dfinal) > 0;
 }
+/* The same loops with the reference's own vector ORs (BitSet.cc:8-21: W = 2 `_mm_or_si128`, W = 4 `_mm256_or_si256`, unaligned
+ * loads) - what SURVEY.md 8(d)(ii) asks the CPU baseline to be.  Same results bit for bit (tests/test_oracle_golden.py runs the
+ * golden corpora through both); taken when the CPU has AVX2 unless rro_set_simd(0) turned it off. */
+#if defined(__x86_64__)
+#include <immintrin.h>
+__attribute__((target("avx2"))) static int accepts_w4_avx2(const rro_nfa *n, const uint8_t *s, size_t len) {
+    const uint64_t *T = n->dense; const uint32_t N = n->states_n;
+    uint64_t cur[4] = {0, 0, 0, 0};
+    cur[n->initial >> 6] = 1ULL << (n->initial & 63);
+    for (size_t i = 0; i < len; i++) {
+        unsigned c = s[i];
+        if (c == 0 || c >= 0x80) return 0;
+        const uint64_t *col = T + (size_t)c * N * 4;
+        __m256i nw = _mm256_setzero_si256();
+        for (int k = 0; k < 4; k++)
+            for (uint64_t w = cur[k]; w; w &= w - 1)
+                nw = _mm256_or_si256(nw, _mm256_loadu_si256((const __m256i *)(col + (size_t)(k * 64 + __builtin_ctzll(w)) * 4)));
+        _mm256_storeu_si256((__m256i *)cur, nw);
+    }
+    return rro_bs_and_cardinality(4, cur, n->dfinal) > 0;
+}
+__attribute__((target("sse2"))) static int accepts_w2_sse(const rro_nfa *n, const uint8_t *s, size_t len) {
+    const uint64_t *T = n->dense; const uint32_t N = n->states_n;
+    uint64_t cur[2] = {0, 0};
+    cur[n->initial >> 6] = 1ULL << (n->initial & 63);
+    for (size_t i = 0; i < len; i++) {
+        unsigned c = s[i];
+        if (c == 0 || c >= 0x80) return 0;
+        const uint64_t *col = T + (size_t)c * N * 2;
+        __m128i nw = _mm_setzero_si128();
+        for (int k = 0; k < 2; k++)
+            for (uint64_t w = cur[k]; w; w &= w - 1)
+                nw = _mm_or_si128(nw, _mm_loadu_si128((const __m128i *)(col + (size_t)(k * 64 + __builtin_ctzll(w)) * 2)));
+        _mm_storeu_si128((__m128i *)cur, nw);
+    }
+    return rro_bs_and_cardinality(2, cur, n->dfinal) > 0;
+}
+#endif
+static int g_simd = -1;                     /* -1: not asked yet, 0: scalar loops, 1: the vector ORs */
+void rro_set_simd(int on) { g_simd = on ? 1 : 0; }
+int rro_simd(void) {
+    if (g_simd < 0) {
+#if defined(__x86_64__)
+        g_simd = __builtin_cpu_supports("avx2") ? 1 : 0;
+#else
+        g_simd = 0;
+#endif
+    }
+    return g_simd;
+}
 /* Sparse class: NFA.cc:77-85 (toUint32Array -> row pointers -> fastunion), full-width state index. */
 static int accepts_sparse(const rro_nfa *n, const uint8_t *s, size_t len) {
     set_t cur = {0, 0, 0}, nxt = {0, 0, 0};
@@ -545,6 +595,10 @@ static int accepts_sparse(const rro_nfa *n, const uint8_t *s, size_t len) {
 
 int rro_accepts(const rro_nfa *n, const uint8_t *s, size_t len) {
     if (n->cls == 1) return accepts_w1(n, s, len);
+#if defined(__x86_64__)
+    if (n->cls == 4 && rro_simd()) return accepts_w4_avx2(n, s, len);
+    if (n->cls == 2 && rro_simd()) return accepts_w2_sse(n, s, len);
+#endif
     if (n->cls) return accepts_wn(n, s, len);
     return accepts_sparse(n, s, len);
 }

@@ -45,6 +45,10 @@ uint32_t rro_row(const rro_nfa *n, uint32_t state, unsigned c, int fwd, uint32_t
 /* regex.h:156-162 + NFA.cc:72-107: whole-string acceptance of s[0..len).  A byte 0x00 or >= 0x80 inside
  * the string makes the string rejected (the reference cannot express the former and is UB on the latter). */
 int rro_accepts(const rro_nfa *n, const uint8_t *s, size_t len);
+/* the BitSet<2> / BitSet<4> step with the reference's vector ORs (BitSet.cc:8-21) or with scalar words: same results; default:
+ * vector when the CPU has AVX2.  rro_simd() -> what is in use. */
+void rro_set_simd(int on);
+int rro_simd(void);
 
 /* Batch form: split bytes[0..nbytes) on '\n' (a trailing fragment without '\n' is a line too), run
  * rro_accepts per line, write 0/1 per line.  Returns the number of lines (may exceed cap; only cap are

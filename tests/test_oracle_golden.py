@@ -148,6 +148,32 @@ def test_corpus_golden_vectors_reproduce():
         assert (len(acc), int(acc.sum()), "%016x" % synth.fnv1a(acc)) == (c["lines"], c["accepted"], c["accept_fnv1a"]), c["name"]
 
 
+def test_vector_or_step_equals_scalar_step(kat):
+    """The oracle's BitSet<2> / BitSet<4> step with the reference's vector ORs (BitSet.cc:8-21: _mm_or_si128, _mm256_or_si256 -
+    what bench.py's cpu_baseline runs where the CPU has AVX2) and with scalar words: the same answers on the known answers of those
+    two classes and on random text."""
+    import random
+    import pyoracle
+    rng = random.Random(5)
+    pats = [k["pattern"] for k in kat["kat"] if 64 < OracleRegex(k["pattern"]).states_n <= 256]
+    assert len(pats) >= 4
+    was = pyoracle.simd()
+    try:
+        for p in pats:
+            o = OracleRegex(p)
+            assert o.set_class in (2, 4)
+            texts = [k2 for k in kat["kat"] if k["pattern"] == p for k2 in k.get("accepts", []) + k.get("rejects", [])]
+            alphabet = "".join(sorted(set("".join(texts)) | set("ab:/.x"))) or "ab"
+            texts += ["".join(rng.choice(alphabet) for _ in range(rng.randint(0, 90))) for _ in range(300)]
+            got = []
+            for on in (False, True):
+                pyoracle.set_simd(on)
+                got.append([o.accepts(t) for t in texts])
+            assert got[0] == got[1], p
+    finally:
+        pyoracle.set_simd(was)
+
+
 def test_oracle_is_clean_under_asan_and_ubsan(tmp_path):
     """Sanitizers run on the CPU build only: compile the oracle with -fsanitize=address,undefined and compile a
     batch of patterns (incl. the 7786-state keyword set and every error path) + match a few strings."""
