@@ -353,16 +353,19 @@ def main():
 
     accepted = int(regex.match_corpus(corpus).sum(dtype=torch.int64).item())
     # the same launches on the stride-2 table AS NUMBERED (a second regex that is forbidden the order search), so that the record
-    # carries what the profiled order is worth on this box: two alternating rounds of ten launches each, after the
+    # carries what the profiled order is worth on this box: three alternating rounds of ten launches each, after the
     # timed region; rank 0 at N = 1 only
     order_ab = None
     if rank == 0 and world == 1 and regex.table_order is not None:
         plain = rr.RRegex(pattern, getattr(rr, ENGINES[args.engine]), device=local_rank)
         plain.set_background_order(False)
-        for _ in range(3):
+        for _ in range(10):                                # (the GPU idled while `plain` was compiled on the host: both tables warm before the rounds)
             plain.match_corpus_bits(corpus, out=out)
+            regex.match_corpus_bits(corpus, out=out)
+        torch.cuda.synchronize()
         sums = {"ordered": [], "numbered": []}
-        for _ in range(2):
+        rounds = []
+        for _ in range(3):
             for name, r_ in (("ordered", regex), ("numbered", plain)):
                 ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
                 for a, b in ev2:
@@ -370,9 +373,12 @@ def main():
                     r_.match_corpus_bits(corpus, out=out)
                     b.record()
                 torch.cuda.synchronize()
-                sums[name] += [a.elapsed_time(b) for a, b in ev2]
+                ms = [a.elapsed_time(b) for a, b in ev2]
+                sums[name] += ms
+                rounds.append((name, round(sum(ms) / len(ms), 4)))
         assert plain.table_order is None
         order_ab = {k: round(sum(v) / len(v), 4) for k, v in sums.items()}
+        order_ab["rounds"] = rounds
         del plain
     if rank == 0:
         avg_kernel_s = sum(kernel_ms) / len(kernel_ms) / 1e3
