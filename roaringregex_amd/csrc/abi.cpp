@@ -1261,7 +1261,7 @@ int rrx_search_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_star
     }
     rc = chunk_index(c, stream);
     if (rc) return rc;
-    int e = dev::search_chunks(*ct, c->has_high, c->d_bytes, c->nbytes, c->d_chunk_base, c->nchunks, d_start, d_end, stream);
+    int e = dev::search_chunks(*ct, c->has_high, c->d_bytes, c->nbytes, c->d_chunk_base, c->nchunks, c->nlines, d_start, d_end, stream);
     if (e) return hip_fail((hipError_t)e, "search_chunks launch");
     return RRX_OK;
 }

@@ -238,7 +238,8 @@ size_t search_chunk_bytes();                             // bytes of text per wa
 size_t search_chunks_lds_bytes(const SearchChunkDevice &p);
 // chunk_base: per-chunk newline prefix in the stripe_base format (bit 63: the chunk begins at the start of a line)
 // clean: the text may hold bytes >= 0x80 (they cannot index the pair table: stepped as 0x00, which no pattern takes either)
-int search_chunks(const SearchChunkDevice &p, bool clean, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
+// nlines: lines of the corpus (picks the build for chunks that hold more lines than the staging array: 5-byte lines)
+int search_chunks(const SearchChunkDevice &p, bool clean, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks, size_t nlines,
                   uint32_t *match_start, uint32_t *match_end, void *stream);
 // all matches: count[line], then (with the caller's exclusive prefix `first`) the matches of line i at first[i], first[i] + 1, ...
 int search_chunks_count(const SearchChunkDevice &p, bool clean, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,

@@ -135,7 +135,11 @@ __device__ __forceinline__ uint64_t chunk_lookback(uint64_t *status, uint32_t *t
 // MODE kCount: match_start[line] = number of matches of the line (match_end unused).
 // MODE kFill : match_start/match_end[first[line] + k] = k-th match of the line.
 // MODE kAll  : the same, with first[] produced here as well (all.first_out) and the slots bounded by all.cap.
-template <int MODE, int FORM>
+// MULTI (kFirst only): built for corpora whose 16-KiB chunks hold more lines than the staging array (5-byte lines: 3277 against 1728):
+// the lines are taken in WINDOWS of kStageLines ordinals, each parked, taken a line per lane and written out in turn.  That keeps the
+// event words alive through the follow loop - 16 registers, 14-20 % of the rate on every other corpus - so it is a build of its own,
+// chosen by the launcher from the corpus' mean line length; the plain build takes a chunk that overflows through the wave-wide loop.
+template <int MODE, int FORM, bool MULTI = false>
 __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void search_chunks_kernel(SearchChunkDevice prog, uint32_t clean, const uint8_t *__restrict__ bytes, size_t nbytes,
                                                                           const uint64_t *__restrict__ chunk_base, size_t nchunks,
                                                                           const uint64_t *__restrict__ first,
@@ -333,13 +337,14 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     };
     // kFirst: (line ordinal, start, end); kCount: (line ordinal, count, -); kFill: (slot relative to F0, start, end)
     // staged packed as start | end << 16 when both fit 16 bits (kNone stays kNone); anything else goes to memory directly
+    uint32_t win_lo = 0;                                          // MULTI: first ordinal of the window being staged (idx is relative to it; wave-uniform)
     auto emit = [&](uint32_t idx, uint32_t v0, uint32_t v1) {
         const bool staged = idx < kStageLines;
         if (MODE == kCount) { if (staged) st_s[idx] = v0; else match_start[base_line + idx] = v0; return; }
         const bool fits = v0 == kNone || v1 < (MODE == kFirst ? 0x8000u : 0xffffu);      // (v0 <= v1; kFirst: bit 31 of a staged entry marks a PARKED hit)
         if (staged) st_s[idx] = v0 == kNone ? kNone : fits ? (v0 | v1 << 16) : kDirect;
         if (!staged || !fits) {
-            const uint64_t at = ((MODE == kFill || MODE == kAll) ? F0 : base_line) + idx;
+            const uint64_t at = ((MODE == kFill || MODE == kAll) ? F0 : base_line + win_lo) + idx;
             if (MODE != kAll || at < all.cap) { match_start[at] = v0; match_end[at] = v1; }
         }
     };
@@ -365,6 +370,8 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     bool owned = fresh, decided = false;                          // the current line: is it mine; kFirst: has its match been found
     bool fast_count_pass = false;                                 // kCount: the hits added themselves to their lines' staged counts
     bool parked = false;                                          // kFirst: the hits of my bytes are parked in the staging array (wave-uniform)
+    bool fh_valid = false;                                        // MULTI: the hit the follow loop found for my open last line
+    uint32_t fh_pos = 0, fh_anchored = 0, fh_ord = 0, fh_ls = 0;
     if constexpr (MODE == kAll && !COUNTING) { if (fresh) set_first(ord0, lane_base); }
     const uint32_t my_rel = (uint32_t)(my - cstart), my_end_rel = (uint32_t)(my_end - cstart);
     uint32_t ls = my_rel;                                         // its first byte (valid if owned)
@@ -375,6 +382,11 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
         if (!owned) return;
         if constexpr (MODE == kCount) { cnt++; return; }
         if constexpr (COUNTING) { emitted++; return; }
+        if constexpr (MULTI) {                                    // (only the follow loop comes here: the hit of my open last line, kept for its window)
+            fh_valid = true; fh_pos = pos; fh_anchored = f & 1u; fh_ord = ord; fh_ls = ls;
+            decided = true;
+            return;
+        }
         const uint32_t at = MODE == kFirst ? ord : MODE == kAll ? lane_base + emitted : slot_base(ord) + cnt;
         const uint32_t lower = MODE == kFirst ? ls : lb;
         if (f == 3u) emit(at, lower - ls, pos + 1 - ls);          // accepted from the restart point itself: it starts there
@@ -390,7 +402,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
         else { cnt++; emitted++; lb = pos + 1; }
     };
     auto on_newline = [&](uint32_t pos) {
-        if constexpr (MODE == kFirst) { if (owned && !decided && ord >= kStageLines) emit(ord, kNone, kNone); }      // (staged lines default to "none")
+        if constexpr (MODE == kFirst && !MULTI) { if (owned && !decided && ord >= kStageLines) emit(ord, kNone, kNone); }      // (staged lines default to "none")
         if constexpr (MODE == kCount) { if (owned) emit(ord, cnt, 0u); }
         ord++;
         ls = pos + 1; lb = ls; cnt = 0;
@@ -499,7 +511,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
         owned = fresh || nl > 0;
     } else {
     bool fast_first = false, fast_count = false;
-    if constexpr (MODE == kFirst) fast_first = hi_ord < (int64_t)kStageLines;      // every line of the chunk has a staged entry ("none" by default)
+    if constexpr (MODE == kFirst) fast_first = MULTI || hi_ord < (int64_t)kStageLines;     // every line of the chunk has a staged entry ("none" by default; MULTI: window by window)
     if constexpr (MODE == kCount) fast_count = hi_ord < (int64_t)kStageLines;      // ... (0 by default)
     if (fast_count) {
         fast_count_pass = true;
@@ -548,7 +560,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
                 const uint32_t o = run_ord + (uint32_t)__popc(above);
                 const uint32_t l = above ? my_rel + (uint32_t)(16 * i) + ((uint32_t)(31 - __ffs((int)above)) >> 1) + 1u : run_ls;
                 last_hit_end = pos + 1u;
-                st_s[o] = 0x80000000u | anchored << 30 | l << 16 | (pos + 1u - l);
+                if (!MULTI || o < kStageLines) st_s[o] = 0x80000000u | anchored << 30 | l << 16 | (pos + 1u - l);       // (MULTI: window 0 here, the others behind the follow loop)
             }
             if (nlm) { run_ord += (uint32_t)__popc(nlm); run_ls = my_rel + (uint32_t)(16 * i) + ((uint32_t)(31 - __ffs((int)nlm)) >> 1) + 1u; }
         }
@@ -696,8 +708,8 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
                     uint32_t stop = acc & ~(acc >> 1) & 0x55555555u;
                     if constexpr (MODE == kFirst) stop |= (acc >> 1) & 0x55555555u;
                     if (stop) acc &= ~((1u << (31 - __clz((int)stop))) - 1u);
-                    // (first match: at most one hit is left; one word per turn: at most four)
-                    reserve_for((uint32_t)__popc((acc >> 1) & ~acc & 0x55555555u));           // my hits whose start is not known (fields equal to 2)
+                    // (first match: at most one hit is left; one word per turn: at most four; MULTI keeps the hit for its window: no job here)
+                    if constexpr (!MULTI) reserve_for((uint32_t)__popc((acc >> 1) & ~acc & 0x55555555u));       // my hits whose start is not known (fields equal to 2)
                     follow_events(acc, wrel);
                 }
             }
@@ -708,8 +720,77 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
                 follow_events(acc, wrel);
             }
         }
+        // ---- 4b''. MULTI: the same window by window; every window is written out here
+        if constexpr (MULTI) {
+            auto park_window = [&]() {                                                // my hits whose ordinal lies in the window (as 4a did for window 0)
+                uint32_t run_ord = ord0, run_ls = my_rel;
+#pragma unroll
+                for (int i = 0; i < kEv; i++) {
+                    const uint32_t evw = ev[i];
+                    const uint32_t nlm = evw & ~(evw >> 1) & 0x55555555u;
+                    uint32_t hm = evw & 0xaaaaaaaau;
+                    while (hm) {
+                        const int zb = __clz((int)hm);
+                        hm &= ~(0x80000000u >> zb);
+                        const uint32_t anchored = (evw >> (30 - zb)) & 1u;
+                        const uint32_t above = zb ? nlm & ~(0xffffffffu >> zb) : 0u;
+                        const uint32_t pos = my_rel + (uint32_t)(16 * i) + (uint32_t)(zb >> 1);
+                        const uint32_t o = run_ord + (uint32_t)__popc(above) - win_lo;
+                        const uint32_t l = above ? my_rel + (uint32_t)(16 * i) + ((uint32_t)(31 - __ffs((int)above)) >> 1) + 1u : run_ls;
+                        if (o < kStageLines) st_s[o] = 0x80000000u | anchored << 30 | l << 16 | (pos + 1u - l);
+                    }
+                    if (nlm) { run_ord += (uint32_t)__popc(nlm); run_ls = my_rel + (uint32_t)(16 * i) + ((uint32_t)(31 - __ffs((int)nlm)) >> 1) + 1u; }
+                }
+            };
+            for (win_lo = 0;; win_lo += kStageLines) {                                // (wave-uniform)
+                if (win_lo) park_window();
+                // the hit the follow loop found for my open last line, if that line is in this window
+                if (fh_valid && fh_ord - win_lo < kStageLines) {
+                    const uint32_t rel = fh_ord - win_lo, endrel = fh_pos + 1u - fh_ls;
+                    if (endrel < 0x8000u) st_s[rel] = 0x80000000u | fh_anchored << 30 | fh_ls << 16 | endrel;
+                    else if (fh_anchored) emit(rel, 0u, endrel);                      // (a match that ends 32 KiB into its line: to memory directly)
+                    else {
+                        const size_t s0 = reverse_walk(t, bytes, cstart + fh_ls, cstart + fh_pos + 1);
+                        emit(rel, (uint32_t)(s0 - cstart) - fh_ls, endrel);
+                    }
+                }
+                const int64_t first_rel = (int64_t)lo_ord > (int64_t)win_lo ? (int64_t)lo_ord - win_lo : 0;
+                const int64_t last_rel = hi_ord - (int64_t)win_lo < (int64_t)kStageLines - 1 ? hi_ord - (int64_t)win_lo : (int64_t)kStageLines - 1;
+                for (int64_t j0 = first_rel; j0 <= last_rel; j0 += 64) {              // (wave-uniform)
+                    const int64_t j = j0 + lane;
+                    const uint32_t v = j <= last_rel ? st_s[j] : kNone;
+                    const bool is_parked = v != kNone && v != kDirect && (v >> 31) != 0u;
+                    const uint32_t l = (v >> 16) & 0x3fffu, endrel = v & 0xffffu;
+                    const bool push = is_parked && !((v >> 30) & 1u);
+                    if (is_parked && !push) st_s[j] = endrel << 16;                   // anchored: the match is [0, endrel) of its line
+                    reserve_one(push);
+                    if (push) {
+                        const uint32_t idx = next_slot;
+                        if (idx < kPool) { pool[4 * idx] = l; pool[4 * idx + 1] = l + endrel; pool[4 * idx + 2] = (uint32_t)j; pool[4 * idx + 3] = l; }
+                        else {                                                        // (no room even after a drain)
+                            const size_t s0 = reverse_walk(t, bytes, cstart + l, cstart + l + endrel);
+                            emit((uint32_t)j, (uint32_t)(s0 - cstart) - l, endrel);
+                        }
+                    }
+                }
+                drain(true);
+                // the window's results: whole sectors, consecutive lanes consecutive lines; the entries back to "none" for the next window / chunk
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                for (int64_t j = first_rel + lane; j <= last_rel; j += 64) {
+                    const uint32_t v = st_s[j];
+                    if (v != kDirect) {
+                        match_start[base_line + win_lo + (uint64_t)j] = v == kNone ? kNone : (v & 0xffffu);
+                        match_end[base_line + win_lo + (uint64_t)j] = v == kNone ? kNone : (v >> 16);
+                    }
+                    st_s[j] = kNone;
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if ((int64_t)win_lo + (int64_t)kStageLines > hi_ord) break;
+            }
+            win_lo = 0;
+        }
         // ---- 4b'. kFirst: the parked hits, a LINE per lane
-        if constexpr (MODE == kFirst) {
+        if constexpr (MODE == kFirst && !MULTI) {
             if (parked) {
                 for (int64_t j0 = (int64_t)lo_ord; j0 <= hi_ord; j0 += 64) {          // (wave-uniform; every ordinal of the chunk is staged here)
                     const int64_t j = j0 + lane;
@@ -771,7 +852,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
         if (hi >= (int64_t)kStageLines) hi = (int64_t)kStageLines - 1;
         for (int64_t j = lo_ord + lane; j <= hi; j += 64) all.first_out[base_line + (uint64_t)j] = F0 + st_f[j];
         if (cend == nbytes && lane == 0) { all.first_out[all.nlines] = F0 + wave_matches; *all.total = F0 + wave_matches; }
-    } else {
+    } else if constexpr (!MULTI) {                                // (MULTI wrote its windows inside the pass)
         int64_t hi = hi_ord;
         if (hi >= (int64_t)kStageLines) hi = (int64_t)kStageLines - 1;
         for (int64_t j = lo_ord + lane; j <= hi; j += 64) {
@@ -814,7 +895,7 @@ size_t search_chunks_lds_bytes(const SearchChunkDevice &p) {          // of the 
     const uint32_t n = search_stage_lines(p, kFill);
     return n ? search_table_bytes(p) + (size_t)kSearchWaves * 8 * n : (size_t)kSearchChunkLdsBudget + 1;
 }
-template <int MODE, int FORM>
+template <int MODE, int FORM, bool MULTI = false>
 static int launch_search_chunks_form(const SearchChunkDevice &p, bool clean, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
                                      const uint64_t *first, uint32_t *out0, uint32_t *out1, void *stream, SearchAllArgs all) {
     if (!nchunks) return 0;
@@ -822,7 +903,7 @@ static int launch_search_chunks_form(const SearchChunkDevice &p, bool clean, con
     if (!lines) return (int)hipErrorInvalidValue;
     const size_t lds = search_table_bytes(p) + (size_t)kSearchWaves * 4 * ((MODE == kFill || MODE == kAll) ? 2 : 1) * lines;
     static LdsAttr attr;
-    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(search_chunks_kernel<MODE, FORM>), lds, /*at_zero=*/true);
+    hipError_t e = ensure_dynamic_lds(attr, reinterpret_cast<const void *>(search_chunks_kernel<MODE, FORM, MULTI>), lds, /*at_zero=*/true);
     if (e != hipSuccess) return (int)e;
     // persistent workgroups: the tables are loaded once per workgroup, its waves take chunk after chunk.  One workgroup per
     // CU and no more: a workgroup holds the CU's whole LDS, so a second generation could only start on a CU when all sixteen
@@ -837,7 +918,7 @@ static int launch_search_chunks_form(const SearchChunkDevice &p, bool clean, con
     }
     size_t blocks = (nchunks + kSearchWaves - 1) / kSearchWaves;
     if (blocks > (size_t)cus) blocks = (size_t)cus;
-    hipLaunchKernelGGL((search_chunks_kernel<MODE, FORM>), dim3((unsigned)blocks), dim3(kSearchWaves * 64), lds, (hipStream_t)stream, p, clean ? 1u : 0u, bytes,
+    hipLaunchKernelGGL((search_chunks_kernel<MODE, FORM, MULTI>), dim3((unsigned)blocks), dim3(kSearchWaves * 64), lds, (hipStream_t)stream, p, clean ? 1u : 0u, bytes,
                        nbytes, chunk_base, nchunks, first, out0, out1, lines, all);
     return (int)hipGetLastError();
 }
@@ -847,8 +928,15 @@ static int launch_search_chunks(const SearchChunkDevice &p, bool clean, const ui
     return p.in_global ? launch_search_chunks_form<MODE, kGlobalForm>(p, clean, bytes, nbytes, chunk_base, nchunks, first, out0, out1, stream, all)
                        : launch_search_chunks_form<MODE, kLdsForm>(p, clean, bytes, nbytes, chunk_base, nchunks, first, out0, out1, stream, all);
 }
-int search_chunks(const SearchChunkDevice &p, bool clean, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
+int search_chunks(const SearchChunkDevice &p, bool clean, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks, size_t nlines,
                   uint32_t *match_start, uint32_t *match_end, void *stream) {
+    // a corpus whose chunks hold more lines than the staging array (on average, with a margin): the build that takes them in windows
+    const uint32_t staged = search_stage_lines(p, kFirst);
+    if (nchunks && staged && (double)nlines / (double)nchunks > 0.8 * staged) {
+        SearchAllArgs none;
+        return p.in_global ? launch_search_chunks_form<kFirst, kGlobalForm, true>(p, clean, bytes, nbytes, chunk_base, nchunks, nullptr, match_start, match_end, stream, none)
+                           : launch_search_chunks_form<kFirst, kLdsForm, true>(p, clean, bytes, nbytes, chunk_base, nchunks, nullptr, match_start, match_end, stream, none);
+    }
     return launch_search_chunks<kFirst>(p, clean, bytes, nbytes, chunk_base, nchunks, nullptr, match_start, match_end, stream);
 }
 int search_chunks_count(const SearchChunkDevice &p, bool clean, const uint8_t *bytes, size_t nbytes, const uint64_t *chunk_base, size_t nchunks,
