@@ -1408,6 +1408,33 @@ def test_search_corpus_short_lines_against_the_oracle():
     assert s.numel() == 0 and e.numel() == 0
 
 
+def test_search_first_match_where_a_chunk_overflows_the_staging_array():
+    """First match per line where a 16-KiB chunk holds more lines than the kernel's staging array: (1) a corpus of short lines
+    throughout - the launcher picks the build that takes the lines in windows; (2) a corpus of long lines with one dense stretch of
+    3-byte lines - the plain build, whose overflowing chunks take the wave-wide event loop and write the lines beyond the array one
+    by one.  Against the CPU replay of the two search tables (pinned to the oracle by tests/test_lowering.py), the short lines against
+    the oracle's brute force as well."""
+    from program_replay import SearchReplay
+    rng = random.Random(97)
+    for pattern in ("ab+c", "k(1|10|100)", EMAIL):
+        r = rr.RRegex(pattern)
+        rep = SearchReplay(r.program(rr.PROGRAM_SEARCH_FWD), r.program(rr.PROGRAM_SEARCH_REV))
+        alphabet = "abck01.@ "
+        short = [bytes(rng.choice(alphabet.encode()) for _ in range(rng.choice([0, 1, 2, 3, 3, 4, 6]))) for _ in range(40000)]
+        long_ = [bytes(rng.choice(alphabet.encode()) for _ in range(rng.randint(150, 400))) for _ in range(3000)]
+        for name, lines in (("short throughout", short), ("a dense stretch", long_[:1500] + short[:12000] + long_[1500:])):
+            data = np.frombuffer(b"\n".join(lines) + b"\n", dtype=np.uint8)
+            want = [rep.search(ln) for ln in lines]
+            corpus = rr.Corpus(torch.from_numpy(data.copy()).cuda())
+            assert corpus.num_lines == len(lines)
+            s, e = r.search_corpus(corpus)
+            got = list(zip(s.cpu().tolist(), e.cpu().tolist()))
+            bad = [i for i, (g, w) in enumerate(zip(got, want)) if g != w]
+            assert not bad, (pattern, name, bad[:3], got[bad[0]], want[bad[0]])
+        ws, we = OracleRegex(pattern).search_lines(b"\n".join(short[:4000]) + b"\n")
+        assert [(int(a), int(b)) for a, b in zip(ws, we)] == [rep.search(ln) for ln in short[:4000]], pattern
+
+
 def test_search_corpus_long_lines_across_stripes():
     """Lines far longer than a stripe (matches found after, at and across stripe boundaries; the walk back to the match
     start crosses them too), checked with the CPU replay of the same two tables, which tests/test_lowering.py pins to
