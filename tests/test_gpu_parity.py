@@ -480,6 +480,9 @@ def test_sampled_table_for_automata_that_do_not_determinise():
                     assert r.sampled_escapes() < len(ls) // 50
                 if name != "hostile":
                     assert not r.sampled_table_retired, name
+            # the one-shot entry of a regex on its sampled table: index pass + table kernel (not the NFA engine's single pass)
+            bits1, n1 = r.match_device_bits(dev)
+            assert n1 == len(want) and (_bits_to_bytes(bits1, n1) == want).all(), (pattern[-24:], name, "one-shot")
         torch.cuda.synchronize()
         r.match_corpus_bits(corpus)                                 # (the launch that looks at the hostile launches' count)
         assert r.sampled_table_retired and r.sampled_table is None
