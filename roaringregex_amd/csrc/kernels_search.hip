@@ -364,8 +364,16 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     constexpr int kFollowHits = 4;
     uint32_t fh[kFollowHits];
     uint32_t nfh = 0;
+    uint32_t wave_matches = 0;                                    // kAll: matches of the chunk (known between its two passes)
     auto run_pass = [&](auto counting_tag) {
     constexpr bool COUNTING = decltype(counting_tag)::value;
+    // (r4) kAll, placing pass, when the chunk's lines and matches all have a staged entry: a match is only PARKED at its slot by its own
+    // lane (anchored << 31 | line start << 17 | match end relative to the line start) in a loop of the lane's own - no ballot, no
+    // reservation, no walk job - and the slots are then taken 64 at a time, a match per lane (place_by_slot, behind the follow loop):
+    // the lower bound of a match is the end of the match in the slot before if that is of the same line; an anchored match becomes
+    // its result, the others are pooled for the walk.
+    bool fast_place = false;
+    if constexpr (MODE == kAll && !COUNTING) fast_place = __builtin_amdgcn_readfirstlane((int)(hi_ord < (int64_t)kStageLines && wave_matches <= kStageLines)) != 0;     // (wave-uniform: a scalar)
     e = e_fwd; ord = ord0; emitted = 0;
     bool owned = fresh, decided = false;                          // the current line: is it mine; kFirst: has its match been found
     bool fast_count_pass = false;                                 // kCount: the hits added themselves to their lines' staged counts
@@ -389,6 +397,18 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
         }
         const uint32_t at = MODE == kFirst ? ord : MODE == kAll ? lane_base + emitted : slot_base(ord) + cnt;
         const uint32_t lower = MODE == kFirst ? ls : lb;
+        if (MODE == kAll && fast_place && pos + 1 - ls < 0x1fff0u) {      // (at < kStageLines: every match of the chunk is staged)
+            st_s[at] = (f & 1u) << 31 | ls << 17 | (pos + 1 - ls);
+            cnt++; emitted++; lb = pos + 1;
+            return;
+        }
+        if (MODE == kAll && fast_place) {                         // a match that ends 128 KiB into its line: placed here and now, alone
+            const size_t s0 = f == 3u ? cstart + lower : reverse_walk(t, bytes, cstart + lower, cstart + pos + 1);
+            emit(at, (uint32_t)(s0 - cstart) - ls, pos + 1 - ls);
+            st_s[at] = kDirect;                                   // (not a parked record: place_by_slot leaves it alone)
+            cnt++; emitted++; lb = pos + 1;
+            return;
+        }
         if (f == 3u) emit(at, lower - ls, pos + 1 - ls);          // accepted from the restart point itself: it starts there
         else {
             const uint32_t idx = next_slot++;
@@ -568,6 +588,23 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
         ord = run_ord; ls = run_ls; lb = run_ls; cnt = 0;
         owned = nl ? run_ls < my_end_rel : fresh;                     // a line that starts at my_end is the next lane's
         decided = last_hit_end > run_ls;                              // my open last line has its match already
+    } else if (fast_place) {
+        // every event in byte order, in the lane's own loop: a '\n' sets the next line's first slot, a hit is parked at its slot (on_hit)
+#pragma unroll
+        for (int i = 0; i < kEv; i++) {
+            uint32_t m = ev[i];
+            while (m) {
+                const int z = __clz((int)m) >> 1;
+                const uint32_t f = (m >> (30 - 2 * z)) & 3u;
+                m &= ~(3u << (30 - 2 * z));
+                const uint32_t pos = my_rel + (uint32_t)(16 * i + z);
+                if (f == 1u) on_newline(pos);
+                else if (owned) {                                 // (inside my own bytes a match ends less than 16 KiB into its line: always parked)
+                    st_s[lane_base + emitted] = (f & 1u) << 31 | ls << 17 | (pos + 1 - ls);
+                    cnt++; emitted++; lb = pos + 1;
+                }
+            }
+        }
     } else {
 #pragma unroll
     for (int i = 0; i < kEv; i++) {
@@ -613,7 +650,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
                 for (int j = 0; j < kFollowHits; j++)
                     if ((uint32_t)j < nfh && (fh[j] & 3u) == 2u) mine++;
             }
-            reserve_for(mine);
+            if (!fast_place) reserve_for(mine);
         }
         if (phase == 1 && nfh <= (uint32_t)kFollowHits) {         // the counting pass has been there: its hits, in order
 #pragma unroll
@@ -709,7 +746,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
                     if constexpr (MODE == kFirst) stop |= (acc >> 1) & 0x55555555u;
                     if (stop) acc &= ~((1u << (31 - __clz((int)stop))) - 1u);
                     // (first match: at most one hit is left; one word per turn: at most four; MULTI keeps the hit for its window: no job here)
-                    if constexpr (!MULTI) reserve_for((uint32_t)__popc((acc >> 1) & ~acc & 0x55555555u));       // my hits whose start is not known (fields equal to 2)
+                    if constexpr (!MULTI) { if (!fast_place) reserve_for((uint32_t)__popc((acc >> 1) & ~acc & 0x55555555u)); }     // my hits whose start is not known (fields equal to 2)
                     follow_events(acc, wrel);
                 }
             }
@@ -811,6 +848,36 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
                 }
             }
         }
+        // ---- 4b3. kAll: the parked matches, a MATCH per lane (place_by_slot)
+        if constexpr (MODE == kAll && !COUNTING) {
+            if (fast_place) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                uint32_t carry = kDirect;                                             // the record of the slot before this round's first (none yet)
+                for (uint32_t k0 = 0; k0 < wave_matches; k0 += 64) {                  // (wave-uniform)
+                    const uint32_t k = k0 + (uint32_t)lane;
+                    const bool have = k < wave_matches;
+                    const uint32_t rec = have ? st_s[k] : kDirect;
+                    uint32_t prev = __shfl_up(rec, 1, 64);
+                    if (lane == 0) prev = carry;
+                    carry = __shfl(rec, 63, 64);
+                    const bool is_rec = have && rec != kDirect;
+                    const uint32_t l = (rec >> 17) & 0x3fffu, endrel = rec & 0x1ffffu;
+                    // the lower bound of my match: the end of the match before it if that one is of the same line (same line start)
+                    const uint32_t lb_rel = (prev != kDirect && ((prev >> 17) & 0x3fffu) == l) ? (prev & 0x1ffffu) : 0u;
+                    const bool push = is_rec && !(rec >> 31);
+                    reserve_one(push);
+                    if (is_rec && !push) emit(k, lb_rel, endrel);                     // it starts at the restart point
+                    if (push) {
+                        const uint32_t idx = next_slot;
+                        if (idx < kPool) { pool[4 * idx] = l + lb_rel; pool[4 * idx + 1] = l + endrel; pool[4 * idx + 2] = k; pool[4 * idx + 3] = l; }
+                        else {                                                        // (no room even after a drain)
+                            const size_t s0 = reverse_walk(t, bytes, cstart + l + lb_rel, cstart + l + endrel);
+                            emit(k, (uint32_t)(s0 - cstart) - l, endrel);
+                        }
+                    }
+                }
+            }
+        }
         // ---- 4c. the walks still waiting
         if constexpr (kWalks) drain(true);
     }
@@ -818,7 +885,6 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     if constexpr (MODE == kFirst) { if (owned && !decided && ord >= kStageLines) emit(ord, kNone, kNone); }
     if constexpr (MODE == kCount) { if (owned) { if (fast_count_pass) atomicAdd(&st_s[ord], cnt); else emit(ord, cnt, 0u); } }
     };      // run_pass
-    uint32_t wave_matches = 0;                                    // kAll: matches of the chunk
     if constexpr (MODE == kAll) {
         run_pass(std::true_type{});
         uint32_t incl_m = emitted;
