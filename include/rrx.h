@@ -160,7 +160,9 @@ int rrx_bitmap_to_bytes(int device, const uint32_t *d_accept_bits, size_t nlines
  * string i of the corpus: the substring [d_start[i], d_end[i]) (offsets relative to the start of the string) that the
  * pattern accepts as a whole string (regex.h:156-162) with the smallest end, and among those the smallest start;
  * 0xFFFFFFFF in both when no substring is accepted.  Bytes the pattern cannot match (including NUL and >= 0x80) are
- * ordinary text here.  RRX_ERR_UNSUPPORTED when the two search tables do not fit the device.                     */
+ * ordinary text here.  One kernel (kernels_search.hip) for every pattern: its forward table in LDS when it fits, in HBM/L2
+ * otherwise; RRX_ERR_UNSUPPORTED only when the REVERSE table does not fit 64 KiB of LDS, the forward table has more than 65534
+ * rows, or its stride-2 form more than 256 MiB.  A pattern that accepts the empty string matches [0, 0) in every string.  */
 int rrx_search_corpus(const rrx_regex *re, const rrx_corpus *corpus, uint32_t *d_start, uint32_t *d_end, void *stream);
 /* ALL lazy matches of every string, left to right (what the reference's CLI is documented to print, README.md:30): the
  * k-th match of a string is the search above applied to the rest of the string after the previous match (one byte
