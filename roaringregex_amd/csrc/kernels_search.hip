@@ -367,13 +367,14 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     uint32_t wave_matches = 0;                                    // kAll: matches of the chunk (known between its two passes)
     auto run_pass = [&](auto counting_tag) {
     constexpr bool COUNTING = decltype(counting_tag)::value;
-    // (r4) kAll, placing pass, when the chunk's lines and matches all have a staged entry: a match is only PARKED at its slot by its own
+    // (r4) kAll, placing pass, when the chunk's matches all have a staged entry: a match is only PARKED at its slot by its own
     // lane (anchored << 31 | line start << 17 | match end relative to the line start) in a loop of the lane's own - no ballot, no
     // reservation, no walk job - and the slots are then taken 64 at a time, a match per lane (place_by_slot, behind the follow loop):
     // the lower bound of a match is the end of the match in the slot before if that is of the same line; an anchored match becomes
     // its result, the others are pooled for the walk.
     bool fast_place = false;
-    if constexpr (MODE == kAll && !COUNTING) fast_place = __builtin_amdgcn_readfirstlane((int)(hi_ord < (int64_t)kStageLines && wave_matches <= kStageLines)) != 0;     // (wave-uniform: a scalar)
+    // (the lines need not all be staged: the first slot of a line beyond the array goes to memory directly, as in the other path)
+    if constexpr (MODE == kAll && !COUNTING) fast_place = __builtin_amdgcn_readfirstlane((int)(wave_matches <= kStageLines)) != 0;     // (wave-uniform: a scalar)
     e = e_fwd; ord = ord0; emitted = 0;
     bool owned = fresh, decided = false;                          // the current line: is it mine; kFirst: has its match been found
     bool fast_count_pass = false;                                 // kCount: the hits added themselves to their lines' staged counts
