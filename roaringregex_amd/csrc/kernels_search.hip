@@ -374,7 +374,9 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     // its result, the others are pooled for the walk.
     bool fast_place = false;
     // (the lines need not all be staged: the first slot of a line beyond the array goes to memory directly, as in the other path)
-    if constexpr (MODE == kAll && !COUNTING) fast_place = __builtin_amdgcn_readfirstlane((int)(wave_matches <= kStageLines)) != 0;     // (wave-uniform: a scalar)
+    // A match whose slot lies beyond the array is placed by its lane alone, there and then (a chunk with a match per byte: 16384).
+    if constexpr (MODE == kAll && !COUNTING) fast_place = true;
+    const bool all_staged = __builtin_amdgcn_readfirstlane((int)(wave_matches <= kStageLines)) != 0;       // (kAll; wave-uniform: a scalar)
     e = e_fwd; ord = ord0; emitted = 0;
     bool owned = fresh, decided = false;                          // the current line: is it mine; kFirst: has its match been found
     bool fast_count_pass = false;                                 // kCount: the hits added themselves to their lines' staged counts
@@ -398,15 +400,15 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
         }
         const uint32_t at = MODE == kFirst ? ord : MODE == kAll ? lane_base + emitted : slot_base(ord) + cnt;
         const uint32_t lower = MODE == kFirst ? ls : lb;
-        if (MODE == kAll && fast_place && pos + 1 - ls < 0x1fff0u) {      // (at < kStageLines: every match of the chunk is staged)
+        if (MODE == kAll && fast_place && at < kStageLines && pos + 1 - ls < 0x1fff0u) {
             st_s[at] = (f & 1u) << 31 | ls << 17 | (pos + 1 - ls);
             cnt++; emitted++; lb = pos + 1;
             return;
         }
-        if (MODE == kAll && fast_place) {                         // a match that ends 128 KiB into its line: placed here and now, alone
+        if (MODE == kAll && fast_place) {                         // beyond the array, or a match that ends 128 KiB into its line: placed here and now, alone
             const size_t s0 = f == 3u ? cstart + lower : reverse_walk(t, bytes, cstart + lower, cstart + pos + 1);
             emit(at, (uint32_t)(s0 - cstart) - ls, pos + 1 - ls);
-            st_s[at] = kDirect;                                   // (not a parked record: place_by_slot leaves it alone)
+            if (at < kStageLines) st_s[at] = kDirect;             // (not a parked record: place_by_slot leaves it alone)
             cnt++; emitted++; lb = pos + 1;
             return;
         }
@@ -600,7 +602,9 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
                 m &= ~(3u << (30 - 2 * z));
                 const uint32_t pos = my_rel + (uint32_t)(16 * i + z);
                 if (f == 1u) on_newline(pos);
-                else if (owned) {                                 // (inside my own bytes a match ends less than 16 KiB into its line: always parked)
+                else if (!all_staged) on_hit(pos, f);
+                else if (owned) {                                 // (every match of the chunk has a slot in the array, and inside my own bytes a match ends
+                                                                  //  less than 16 KiB into its line: parked without further ado)
                     st_s[lane_base + emitted] = (f & 1u) << 31 | ls << 17 | (pos + 1 - ls);
                     cnt++; emitted++; lb = pos + 1;
                 }
@@ -854,9 +858,10 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
             if (fast_place) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 uint32_t carry = kDirect;                                             // the record of the slot before this round's first (none yet)
-                for (uint32_t k0 = 0; k0 < wave_matches; k0 += 64) {                  // (wave-uniform)
+                const uint32_t staged_matches = wave_matches < kStageLines ? wave_matches : kStageLines;
+                for (uint32_t k0 = 0; k0 < staged_matches; k0 += 64) {                // (wave-uniform)
                     const uint32_t k = k0 + (uint32_t)lane;
-                    const bool have = k < wave_matches;
+                    const bool have = k < staged_matches;
                     const uint32_t rec = have ? st_s[k] : kDirect;
                     uint32_t prev = __shfl_up(rec, 1, 64);
                     if (lane == 0) prev = carry;
