@@ -110,6 +110,15 @@ while done < npat:
                     print("MISMATCH search_all", repr(p), "mix", mix, "cap", cap, "matches", int(ms.numel()), int(f2[-1]), flush=True)
                     sys.exit(1)
                 checked += 1
+            # ... and against the oracle's brute force where the lines are short (it is cubic in the line length)
+            if mix in ("short", "empty-heavy") and len(arr) <= 50000:
+                wc, ws, we = o.search_all(data)
+                ok = np.array_equal(cnt.cpu().numpy().astype(np.uint32), wc) and np.array_equal(ms.cpu().numpy().astype(np.int32), ws) \
+                    and np.array_equal(me.cpu().numpy().astype(np.int32), we)
+                if not ok:
+                    print("MISMATCH search_all against the oracle", repr(p), "mix", mix, "matches", int(ms.numel()), len(ws), flush=True)
+                    sys.exit(1)
+                checked += 1
     # explicit items: the lines as (offset, length) items, with their '\n' as the separator (trim 1) and squeezed together
     # (trim 0, empty lines dropped): the one-call entry (lane per item at these sizes) and an indexed batch (rrx_items: always the
     # stripe-wise kernel when the batch admits it)
