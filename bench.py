@@ -37,6 +37,9 @@ WORKLOADS = {
     "arepeat": ("arepeat", "A300", 1 << 30, "configs[3]: a{1,300} (4 GiB over 4 GPUs = 1 GiB per GPU)"),
     "kwlines": ("kwlines", "K1000", 8 << 30, "configs[4](i): k1|...|k1000 over lines k<n> (64 GiB over 8 GPUs = 8 GiB per GPU)"),
     "kwlog": ("kwlog", "K1000C", 8 << 30, "configs[4](ii): .*(k1|...|k1000).* over log lines (8 GiB per GPU)"),
+    # "also report a long-line variant (>= 256 B/line) for C2/C3"
+    "email_long": ("email_long", "EMAIL", 1 << 30, "configs[1], long-line variant: email regex over lines of 290-600 bytes (mean 437)"),
+    "url_long": ("url_long", "U2", 8 << 30, "configs[2], long-line variant: URL regex U2 over lines of 390-740 bytes (mean 575)"),
     # not a BASELINE config: the pattern class only an NFA engine can run (its subset construction has 2^41 sets)
     "nondet": ("ablines", "NONDET", 8 << 30, "extra: (a|b)*a(a|b){40} over lines of a/b (no DFA exists within memory)"),
     "nondet600": ("ablong", "NONDET600", 1 << 30, "extra: (a|b)*a(a|b){600} over lines of 500-900 a/b (604 positions, group-cooperative NFA)"),

@@ -31,7 +31,9 @@ inline uint32_t pick_stripe(size_t nbytes) {
 // a time (k<n> lines of 5.4 bytes, 8 GiB: 4 KiB stripes 3.69 TB/s, 1 KiB stripes 4.53; profiles/r02_short_line_stripes.txt).
 inline uint32_t stripe_for_lines(size_t nbytes, size_t avg_line) {
     uint32_t want = pick_stripe(nbytes);
-    while (want < kMaxStripe && avg_line * 16 > want && nbytes / (2 * (size_t)want) >= ((size_t)1 << 17)) want *= 2;
+    // ... but never below 2^18 lanes: 256 workgroups of 1024 lanes, one per CU (r4: the floor was 2^17 and 1 GiB of 440-byte lines got 8 KiB
+    // stripes, i.e. 128 workgroups on 256 CUs: 2.6 TB/s against 4.4 with 4 KiB stripes; tools/probe/long_line_stripes.sh)
+    while (want < kMaxStripe && avg_line * 16 > want && nbytes / (2 * (size_t)want) >= ((size_t)1 << 18)) want *= 2;
     while (want > 1024 && (avg_line + 1) * 128 < want) want /= 2;      // (512-byte stripes are for explicit requests)
     return want;
 }

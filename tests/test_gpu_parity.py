@@ -357,6 +357,33 @@ def test_full_size_kwlog_config_properties():
     _full_size_properties("kwlog", 4, K1000_CONTAINS, 8 << 30, (rr.ENGINE_DFA2, rr.ENGINE_DFA, rr.ENGINE_NFA), (0, 3, 4098, 8191), (0.2, 0.8))
 
 
+def test_long_line_variants_of_the_email_and_url_configs():
+    """"also report a long-line variant (>= 256 B/line) for C2/C3" - the corpora bench.py times as email_long and
+    url_long (lines of 290-600 and 390-740 bytes, half of them corrupted), 1 GiB each: every engine the same bitmap, the oracle on
+    sampled chunks, and the first-match search on a 64 MiB slice against the accept bits (an accepted line's first match... need
+    not be the whole line, but a line has a match iff some substring is accepted, and the whole line is one)."""
+    for kind, pattern in (("email_long", EMAIL), ("url_long", U2)):
+        _full_size_properties(kind, 2, pattern, 1 << 30, (rr.ENGINE_DFA2, rr.ENGINE_DFA, rr.ENGINE_NFA), (0, 511, 1023), (0.4, 0.6))
+        import synth
+        host = synth.corpus(kind, 2, 64 << 20)
+        dev = torch.from_numpy(host).cuda()
+        corpus = rr.Corpus(dev)
+        r = rr.RRegex(pattern)
+        acc = r.match_corpus(corpus)
+        st, en = r.search_corpus(corpus)
+        assert bool(((st >= 0) | (acc == 0)).all()), kind                  # an accepted line holds a match
+        o = OracleRegex(pattern)
+        lines = host[: 1 << 16].tobytes().split(b"\n")[:24]               # (the oracle's brute force is quadratic in the match end)
+        s_, e_ = st[:len(lines)].cpu().tolist(), en[:len(lines)].cpu().tolist()
+        for ln, a, b in zip(lines, s_, e_):
+            if a >= 0:
+                assert o.accepts(ln[a:b]) and not any(o.accepts(ln[a:k]) for k in range(a, b)), (kind, ln, a, b)
+                assert not any(o.accepts(ln[j:k]) for k in range(0, b) for j in range(0, k + 1)) , (kind, ln, a, b)   # no earlier end
+                assert not any(o.accepts(ln[j:b]) for j in range(0, a)), (kind, ln, a, b)                              # no earlier start
+            else:
+                assert not any(o.accepts(ln[j:k]) for k in range(0, min(len(ln), 40) + 1) for j in range(0, k + 1)), (kind, ln)
+
+
 def test_profiled_table_order_changes_no_result():
     """At its first match against a corpus of 64 MiB or more a background thread orders the stride-2 table by a sample of the
     text (rows and columns permuted so that fewer lookups of a half-wave share an LDS bank) and swaps the tables in when it is

@@ -8,7 +8,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
-KIND = {"c1": 1, "email": 2, "url": 3, "arepeat": 4, "kwlines": 5, "kwlog": 6, "ablines": 7, "ablong": 8}
+KIND = {"c1": 1, "email": 2, "url": 3, "arepeat": 4, "kwlines": 5, "kwlog": 6, "ablines": 7, "ablong": 8, "email_long": 9, "url_long": 10}
 
 
 def _lib():
