@@ -85,7 +85,12 @@ int         rrx_order_table(rrx_regex *re, const void *sample, uint32_t lanes, u
  * the pattern's own table, which tells the matches that start at the line start (no walk back to find the start); 0 builds the
  * forward table alone - fewer rows, every match start walked back to - which is also what a product beyond 65534 rows falls
  * back to.  Same results.  Set it before the regex' first search (RRX_ERR_ARG afterwards).                                  */
-enum { RRX_OPT_BACKGROUND_ORDER = 1, RRX_OPT_UNITS_PER_WORKGROUP = 2, RRX_OPT_SAMPLED_TABLE = 3, RRX_OPT_FLUSH_SLOTS = 4, RRX_OPT_SEARCH_ANCHORED = 5 };
+/* RRX_OPT_ITEMS_STRIDE2 (default 1): large batches of explicit items with a separator byte each (rrx_match_extents /
+ * rrx_match_items, trim 1) are stepped two bytes per lookup by a stride-2 table of their own - every byte value an ordinary
+ * symbol, '\n' too, the separator a 129th - where the regex has a stride-2 table; 0 keeps them on the byte-stride items kernel
+ * (which serves trim 0 either way).  Same results.                                                                         */
+enum { RRX_OPT_BACKGROUND_ORDER = 1, RRX_OPT_UNITS_PER_WORKGROUP = 2, RRX_OPT_SAMPLED_TABLE = 3, RRX_OPT_FLUSH_SLOTS = 4, RRX_OPT_SEARCH_ANCHORED = 5,
+       RRX_OPT_ITEMS_STRIDE2 = 6 };
 int         rrx_set_option(rrx_regex *re, int option, int64_t value);
 /* The SAMPLED TABLE (an automaton that does not determinise - AUTO leaves it on the NFA lane engine - over text whose live sets
  * are few, README.md:18-21): the state sets a text sample reaches are interned into a table, every transition the sample and a
@@ -126,6 +131,10 @@ int         rrx_accepts_empty(const rrx_regex *re); /* Processor::operator*() on
 #define RRX_PROGRAM_SAMPLED_DFA 12  /* the sampled table (rrx_learn_table): the DFA layout, then escaped[nstates] (1: the ESCAPE state) */
 #define RRX_PROGRAM_SAMPLED_DFA2 13 /* its stride-2 form as the kernel runs it: the DFA2 layout, byte 2 of an entry = RESULT BITS shifted
                                        in (two per line end: accepted, escaped), byte 3 = those bits                          */
+#define RRX_PROGRAM_DFA2_ITEMS 15 /* the stride-2 table of explicit items with a separator each (rrx_match_extents / rrx_match_items, trim 1):
+                                    [nstates, ncols, start, accepts_empty, 129, column of the code pair[129][129], next2[nstates][ncols]] - codes
+                                    0 ... 127 the byte values ('\n' an ordinary byte), 128 END OF ITEM; entries as in the DFA2 layout.  0 words
+                                    where the regex has no stride-2 table or this form does not fit beside the pair table              */
 size_t rrx_program_words(const rrx_regex *re, int kind, uint32_t *out, size_t cap);
 
 /* ---- batch of strings: the replacement for calling get_acceptance_iter(line)++ per string ------------ *

@@ -19,6 +19,7 @@ ENGINE_NFA_BLOCK = 8
 ENGINE_NFA_SPARSE = 10
 PROGRAM_SEARCH_LINE = 9
 PROGRAM_SEARCH_LINE2 = 14
+PROGRAM_DFA2_ITEMS = 15
 PROGRAM_DFA2_ORDER = 11
 PROGRAM_SAMPLED_DFA = 12
 PROGRAM_SAMPLED_DFA2 = 13
@@ -27,6 +28,7 @@ OPT_UNITS_PER_WORKGROUP = 2
 OPT_SAMPLED_TABLE = 3
 OPT_FLUSH_SLOTS = 4
 OPT_SEARCH_ANCHORED = 5
+OPT_ITEMS_STRIDE2 = 6
 
 # every symbol include/rrx.h declares (tests check the library exports exactly these)
 ABI_SYMBOLS = (
@@ -505,6 +507,11 @@ class RRegex:
         """rrx_set_option(RRX_OPT_SEARCH_ANCHORED): False builds the search kernels' forward table without the product that tells
         the matches starting at the line start (fewer rows; every match start is walked back to).  Before the first search."""
         _check(_L.rrx_set_option(self._h, OPT_SEARCH_ANCHORED, 1 if enabled else 0))
+
+    def set_items_stride2(self, enabled):
+        """rrx_set_option(RRX_OPT_ITEMS_STRIDE2): False keeps large batches of explicit items with separators (trim 1) on the
+        byte-stride items kernel instead of the stride-2 table of their own."""
+        _check(_L.rrx_set_option(self._h, OPT_ITEMS_STRIDE2, 1 if enabled else 0))
 
     def set_units_per_workgroup(self, units):
         """rrx_set_option(RRX_OPT_UNITS_PER_WORKGROUP): the stride-2 batch kernel hands its stripes out in units of 64 inside

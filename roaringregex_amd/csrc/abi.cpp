@@ -46,6 +46,10 @@ struct ItemsTableOnDevice {
     void *blob = nullptr;
     dev::LineDfaDevice line;
 };
+struct Items2TableOnDevice {
+    void *blob = nullptr;
+    dev::Dfa2Device dfa2;
+};
 struct SearchTablesOnDevice {
     void *blob = nullptr;
     dev::SearchChunkDevice chunk;      // the stripe-wise kernel's tables (device.hpp)
@@ -213,9 +217,10 @@ struct rrx_regex {
                 const uint32_t row_off = row_slot(v & 0xffffu) * s2 * 4 * R2;
                 for (uint32_t k = 0; k < R2; k++) T2[((size_t)row_slot(st) * s2 + col_slot(col)) * R2 + k] = (row_off + 4 * k) | (v & 0xffff0000u);
             }
-        P.assign(128 * dev::kDfa2PStride, 0);
-        for (unsigned c1 = 0; c1 < 128; c1++)
-            for (unsigned c2 = 0; c2 < 128; c2++) P[c1 * dev::kDfa2PStride + c2] = (uint16_t)(col_slot(dfa2.pair_col[c1 * 128 + c2]) * 4 * R2);
+        const unsigned dim = dfa2.pair_dim;                 // 128; items form: 129 (code 128 = END OF ITEM: a row more, and the pad column 128)
+        P.assign(dim * dev::kDfa2PStride, 0);
+        for (unsigned c1 = 0; c1 < dim; c1++)
+            for (unsigned c2 = 0; c2 < dim; c2++) P[c1 * dev::kDfa2PStride + c2] = (uint16_t)(col_slot(dfa2.pair_col[c1 * dim + c2]) * 4 * R2);
         d.nrows = D2; d.stride = s2 * R2; d.start_off = row_slot(dfa2.start) * s2 * 4 * R2; d.rep_log2 = rep2;
     }
     bool t2_order_applies() const {                      // single-copy tables only: interleaved copies already keep lanes apart
@@ -289,6 +294,10 @@ struct rrx_regex {
     mutable bool search_nullable = false;       // the pattern accepts the empty string: every offset is a match, no table (empty_matches)
     mutable std::map<int, SearchTablesOnDevice> search_on_device;
     mutable std::map<int, ItemsTableOnDevice> items_on_device;
+    mutable std::map<int, Items2TableOnDevice> items2_on_device;
+    mutable Dfa2Program items2_prog;                   // lowered at the first batch of items with separators
+    mutable int items2_state = 0;                      // 0 not tried, 1 there, 2 does not fit
+    std::atomic<int> items_stride2{1};                 // RRX_OPT_ITEMS_STRIDE2 (0: the byte-stride items kernel for trim 1 as well)
     // Scratch of the single-string entries (rrx_match_string / rrx_match_cstr): one grow-only device buffer per device,
     // kept across calls (a hipMalloc + hipFree pair per string cost more than the match itself).  `scratch_mu` is held
     // for the whole call: those entries are synchronous, concurrent callers of one regex take turns.
@@ -361,6 +370,40 @@ struct rrx_regex {
         for (auto &kv : on_device) if (kv.second.blob) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.blob); }
         for (auto &kv : search_on_device) if (kv.second.blob) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.blob); }
         for (auto &kv : items_on_device) if (kv.second.blob) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.blob); }
+        for (auto &kv : items2_on_device) if (kv.second.blob) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.blob); }
+    }
+    // The stride-2 table of explicit items with a separator byte each (trim 1; lower_dfa2's items form): nullptr where the regex
+    // has no stride-2 table or the items form - one symbol more - does not fit the same LDS region.
+    bool items2_program_locked() const {                 // host side (call with `mu` held)
+        if (has_dfa2 && items2_state == 0) {
+            items2_state = lower_dfa2(dfa, 1024, items2_prog, /*items=*/true) &&
+                           (size_t)items2_prog.nstates * (items2_prog.ncols | 1u) * 4 <= dev::kDfa2MaxTable ? 1 : 2;
+        }
+        return items2_state == 1;
+    }
+    bool items2_program() const { std::lock_guard<std::mutex> lock(mu); return items2_program_locked(); }
+    const dev::Dfa2Device *items2_table(int device) const {
+        std::lock_guard<std::mutex> lock(mu);
+        auto it = items2_on_device.find(device);
+        if (it != items2_on_device.end()) return it->second.blob ? &it->second.dfa2 : nullptr;
+        Items2TableOnDevice t;
+        if (items2_program_locked() && hipSetDevice(device) == hipSuccess) {
+            std::vector<uint32_t> T2;
+            std::vector<uint16_t> P;
+            build_dfa2_arrays_of(items2_prog, std::vector<uint32_t>(), std::vector<uint32_t>(), T2, P, t.dfa2);
+            const size_t pb = (P.size() * 2 + 15) & ~(size_t)15;
+            if (pb <= dev::kDfa2PItemsBytes && hipMalloc(&t.blob, dev::kDfa2PItemsBytes + T2.size() * 4) == hipSuccess) {
+                if (hipMemset(t.blob, 0, dev::kDfa2PItemsBytes) != hipSuccess ||
+                    hipMemcpy(t.blob, P.data(), P.size() * 2, hipMemcpyHostToDevice) != hipSuccess ||
+                    hipMemcpy(static_cast<uint8_t *>(t.blob) + dev::kDfa2PItemsBytes, T2.data(), T2.size() * 4, hipMemcpyHostToDevice) != hipSuccess) {
+                    (void)hipFree(t.blob); t.blob = nullptr;
+                }
+            }
+            t.dfa2.P = static_cast<const uint16_t *>(t.blob);
+            t.dfa2.T2 = t.blob ? reinterpret_cast<const uint32_t *>(static_cast<uint8_t *>(t.blob) + dev::kDfa2PItemsBytes) : nullptr;
+        }
+        auto ins = items2_on_device.emplace(device, t);
+        return ins.first->second.blob ? &ins.first->second.dfa2 : nullptr;
     }
     // nullptr: the plain table has too many states for 16-bit row offsets (or there is none)
     const dev::LineDfaDevice *items_table(int device) const {
@@ -883,6 +926,7 @@ int rrx_set_option(rrx_regex *re, int option, int64_t value) {
         return RRX_OK;
     }
     if (option == RRX_OPT_SAMPLED_TABLE) { re->opt_sampled_table.store(value ? 1 : 0); return RRX_OK; }
+    if (option == RRX_OPT_ITEMS_STRIDE2) { re->items_stride2.store(value ? 1 : 0); return RRX_OK; }
     if (option == RRX_OPT_SEARCH_ANCHORED) {
         std::lock_guard<std::mutex> lock(re->mu);
         if (re->search_state != 0) return fail(RRX_ERR_ARG, "the search tables of this regex are built already");
@@ -946,6 +990,13 @@ size_t rrx_program_words(const rrx_regex *re, int kind, uint32_t *out, size_t ca
         } else {                                            // the stride-2 layout (entries: next | result bits << 16 | verdict pairs << 24)
             const Dfa2Program &d = re->sampled_dfa2;
             w = {d.nstates, d.ncols, d.start, d.accepts_empty ? 1u : 0u};
+            for (uint16_t c : d.pair_col) w.push_back(c);
+            w.insert(w.end(), d.next2.begin(), d.next2.end());
+        }
+    } else if (kind == RRX_PROGRAM_DFA2_ITEMS && re->has_dfa2) {
+        if (re->items2_program()) {
+            const Dfa2Program &d = re->items2_prog;
+            w = {d.nstates, d.ncols, d.start, d.accepts_empty ? 1u : 0u, d.pair_dim};
             for (uint16_t c : d.pair_col) w.push_back(c);
             w.insert(w.end(), d.next2.begin(), d.next2.end());
         }
@@ -1406,9 +1457,15 @@ int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, cons
     // the batch can span - what is left of the allocation that holds d_bytes - and the kernels take the real extent from the
     // offsets.  Whether the batch is fit (alignment, no degenerate item, large enough) is decided on the device: the
     // stripe-wise kernel does nothing on an unfit batch and the lane-per-item kernel queued behind it does nothing on a fit one.
-    const dev::LineDfaDevice *items = nullptr;
-    if (re->engine == RRX_ENGINE_DFA && trim <= 1 && nitems >= kItemsStripesMin && !(reinterpret_cast<uintptr_t>(d_accept) & 15))
-        items = re->items_table(device);
+    // (r4) trim 1 on a regex with a stride-2 table: the stride-2 items table (it also serves automata whose byte-stride items table
+    // is beyond the LDS - a{1,300}: 302 rows of 130 columns)
+    const dev::LineDfaDevice *items1 = nullptr;
+    const dev::Dfa2Device *items2 = nullptr;
+    if (re->engine == RRX_ENGINE_DFA && trim <= 1 && nitems >= kItemsStripesMin && !(reinterpret_cast<uintptr_t>(d_accept) & 15)) {
+        if (trim == 1 && re->items_stride2.load()) items2 = re->items2_table(device);
+        if (!items2) items1 = re->items_table(device);
+    }
+    const bool items = items1 || items2;
     size_t bound = 0;
     if (items) {
         hipDeviceptr_t abase = nullptr;
@@ -1443,7 +1500,8 @@ int rrx_match_extents(const rrx_regex *re, int device, const void *d_bytes, cons
         if (rc) return rc;
         uint32_t *d_flag = nullptr;
         int le = dev::items_index_build(bound, d_off, nitems, trim, buf, &d_flag, stream, b, kItemsStripesMinBytes);
-        if (!le) le = dev::items_match(*items, b, bound, nitems, trim, buf, static_cast<uint8_t *>(buf) + ib, d_accept, stream, d_off, d_flag);
+        if (!le) le = items2 ? dev::items_match2(*items2, b, bound, nitems, buf, static_cast<uint8_t *>(buf) + ib, d_accept, stream, d_off, d_flag)
+                             : dev::items_match(*items1, b, bound, nitems, trim, buf, static_cast<uint8_t *>(buf) + ib, d_accept, stream, d_off, d_flag);
         if (!le) rc = match_extents_lanes(re, t, b, d_off, nitems, trim, d_accept, stream, d_flag);
         const int rc2 = re->onepass_done(device, st);            // (whatever was queued: the next user waits for it)
         if (le) return hip_fail((hipError_t)le, "match_items_stripes launch");
@@ -1514,9 +1572,12 @@ int rrx_match_items(const rrx_regex *re, const rrx_items *it, uint8_t *d_accept,
     if (rc) return rc;
     HIP_TRY(hipSetDevice(it->device));
     if (it->stripes && re->engine == RRX_ENGINE_DFA && !(reinterpret_cast<uintptr_t>(d_accept) & 15)) {
-        if (const dev::LineDfaDevice *items = re->items_table(it->device)) {
+        const dev::Dfa2Device *items2 = (it->trim == 1 && re->items_stride2.load()) ? re->items2_table(it->device) : nullptr;
+        const dev::LineDfaDevice *items1 = items2 ? nullptr : re->items_table(it->device);
+        if (items1 || items2) {
             std::lock_guard<std::mutex> lock(it->mu);
-            int le = dev::items_match(*items, it->d_bytes + it->first, it->nbytes, it->nitems, it->trim, it->d_index, it->d_result, d_accept, stream);
+            int le = items2 ? dev::items_match2(*items2, it->d_bytes + it->first, it->nbytes, it->nitems, it->d_index, it->d_result, d_accept, stream)
+                            : dev::items_match(*items1, it->d_bytes + it->first, it->nbytes, it->nitems, it->trim, it->d_index, it->d_result, d_accept, stream);
             if (le) return hip_fail((hipError_t)le, "match_items launch");
             return RRX_OK;
         }

@@ -145,12 +145,18 @@ struct Dfa2Device {
 };
 constexpr uint32_t kDfa2PStride = 130;                // u16 entries per P row
 constexpr uint32_t kDfa2PBytes = 128 * kDfa2PStride * 2;
+// items form (trim 1): code 128 = END OF ITEM - one row more, and column 128 (one of the two pad columns of every row)
+constexpr uint32_t kDfa2PItemsBytes = (129 * kDfa2PStride * 2 + 15) & ~15u;
 // LDS of a stride-2 workgroup: P (32.5 KiB) + one 46 KiB region shared by T2 and the result window = 78.5 KiB, i.e. two
 // 1024-lane workgroups per 160-KiB CU.  Copies of T2 are only made while they leave the window its 16 KiB.
 constexpr uint32_t kDfa2RegionBytes = 46 * 1024;
 constexpr uint32_t kDfa2MaxTable = kDfa2RegionBytes - 4 * 1024;       // a table this large leaves a 4 KiB window
 constexpr uint32_t kDfa2TableBudget = 30 * 1024;                      // T2 with its copies
 
+// explicit items with separators (trim 1) on the stride-2 table of their own (lower_dfa2's items form; P of kDfa2PItemsBytes):
+// the arguments of items_match below
+int items_match2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, size_t nitems, const void *index, void *result, uint8_t *accept, void *stream,
+                 const uint64_t *resolve_off = nullptr, const uint32_t *skip_if = nullptr);
 uint32_t flush_mask_for(size_t nbytes, size_t nlines);      // the stride-2 kernel's common flush period from the mean line length
 int match_stripes_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
                        size_t nstripes, uint32_t *accept, void *stream, uint32_t flush_mask = 31u);

@@ -1232,7 +1232,7 @@ bool lower_search_line2(const SearchLineProgram &s, const uint32_t *column, uint
 }
 
 // ------------------------------------------------------------------------------------------ stride-2 lowering
-bool lower_dfa2(const DfaProgram &d, uint32_t max_cols, Dfa2Program &o) {
+bool lower_dfa2(const DfaProgram &d, uint32_t max_cols, Dfa2Program &o, bool items) {
     o = Dfa2Program();
     const uint32_t D = d.nstates, K = d.ncls, NL = K;            // symbols 0..K-1 = byte classes, K = '\n'
     o.nstates = D; o.start = d.start; o.accepts_empty = d.accepts_empty;
@@ -1267,10 +1267,12 @@ bool lower_dfa2(const DfaProgram &d, uint32_t max_cols, Dfa2Program &o) {
     o.ncols = (uint32_t)col_data.size();
     o.next2.assign((size_t)D * o.ncols, 0);
     for (uint32_t c = 0; c < o.ncols; c++) for (uint32_t s = 0; s < D; s++) o.next2[(size_t)s * o.ncols + c] = col_data[c][s];
-    o.pair_col.assign(128 * 128, 0);
-    auto sym = [&](unsigned c) -> uint32_t { return c == '\n' ? NL : d.cls[c]; };
-    for (unsigned c1 = 0; c1 < 128; c1++)
-        for (unsigned c2 = 0; c2 < 128; c2++) o.pair_col[c1 * 128 + c2] = (uint16_t)sym_pair_col[(size_t)sym(c1) * (K + 1) + sym(c2)];
+    const unsigned dim = items ? 129u : 128u;
+    o.pair_dim = dim;
+    o.pair_col.assign((size_t)dim * dim, 0);
+    auto sym = [&](unsigned c) -> uint32_t { return items ? (c == 128 ? NL : d.cls[c]) : (c == '\n' ? NL : d.cls[c]); };
+    for (unsigned c1 = 0; c1 < dim; c1++)
+        for (unsigned c2 = 0; c2 < dim; c2++) o.pair_col[c1 * dim + c2] = (uint16_t)sym_pair_col[(size_t)sym(c1) * (K + 1) + sym(c2)];
     return true;
 }
 

@@ -81,13 +81,17 @@ struct DfaProgram {
 // a line: verdict of the state, restart).  Pairs of symbols with identical behaviour on every state share a column.
 struct Dfa2Program {
     uint32_t nstates = 0, ncols = 0, start = 0;
-    std::vector<uint16_t> pair_col;         // [128][128]: column of the byte pair (c1, c2)
+    uint32_t pair_dim = 128;                // items form: 129 - code 128 is END OF ITEM, '\n' an ordinary byte
+    std::vector<uint16_t> pair_col;         // [pair_dim][pair_dim]: column of the byte pair (c1, c2)
     std::vector<uint32_t> next2;            // [nstates][ncols]: next state | lines ended (0..2) << 16 | verdicts << 24
     bool accepts_empty = false;             //   (verdicts: oldest line highest)
 };
 // Returns false if there are more than max_cols distinct pair columns.  A sampled table (d.escaped) yields the TWO-BIT form:
 // a line end shifts two result bits in, (accepted, escaped), the counts in byte 2 of an entry are bit counts.
-bool lower_dfa2(const DfaProgram &d, uint32_t max_cols, Dfa2Program &out);
+// items = true: the table for explicit items with a separator byte each (rrx_match_extents / rrx_match_items, trim 1): every byte
+// value is an ordinary symbol of the pattern - '\n' too -, what ends a line is the code 128, which the kernel puts in the place
+// of the bytes the item index marks.
+bool lower_dfa2(const DfaProgram &d, uint32_t max_cols, Dfa2Program &out, bool items = false);
 // Profile-guided ORDER of the stride-2 table's rows and columns in LDS.  The table's entry for (state s, pair column c) sits at
 // word row_slot[s] * (ncols | 1) + col_slot[c], i.e. in LDS bank (row_slot[s] * (ncols | 1) + col_slot[c]) mod 32: the order
 // costs no memory and decides which entries collide when the 32 lanes of a half-wave look up 32 different (state, column)

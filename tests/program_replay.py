@@ -111,6 +111,36 @@ class Dfa2Replay:
         return out[:-1] if drop_last else out
 
 
+class Dfa2ItemsReplay:
+    """The stride-2 table of explicit items with a separator byte each (rrx_program_words kind 15): [D, C, start, accepts_empty, 129,
+    pair_col[129 * 129], next2[D][C]] - codes 0 ... 127 the byte values ('\\n' ordinary), 128 END OF ITEM; entries as in Dfa2Replay."""
+
+    def __init__(self, words):
+        w = np.asarray(words, dtype=np.int64)
+        self.D, self.C, self.start, self.dim = int(w[0]), int(w[1]), int(w[2]), int(w[4])
+        assert self.dim == 129
+        self.pair_col = w[5:5 + 129 * 129]
+        self.next2 = w[5 + 129 * 129:].reshape(self.D, self.C)
+
+    def match_items(self, items):
+        """Verdict per item (bytes objects): the items laid end to end, each followed by its separator, stepped two codes at a time the
+        way the kernel does - a byte >= 0x80 as 0x00, the separator as 128 whatever its value."""
+        seq = []
+        for it in items:
+            seq.extend((c if c < 128 else 0) for c in it)
+            seq.append(128)
+        odd = len(seq) % 2 == 1
+        if odd:
+            seq.append(128)                      # padding: one spurious empty item
+        out, st = [], self.start
+        for i in range(0, len(seq), 2):
+            e = int(self.next2[st, self.pair_col[seq[i] * 129 + seq[i + 1]]])
+            st, lines, verdicts = e & 0xffff, (e >> 16) & 0xff, e >> 24
+            for k in range(lines):
+                out.append((verdicts >> (lines - 1 - k)) & 1)
+        return out[:-1] if odd else out
+
+
 class SampledReplay:
     """The sampled table (rrx_program_words kinds 12 and 13): a DFA with an ESCAPE state - [D, K, start, accepts_empty, cls[256],
     accepting[D], next[D][K], escaped[D]] - and its stride-2 form, whose line ends carry TWO result bits (accepted, escaped).

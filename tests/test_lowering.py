@@ -8,7 +8,7 @@ import pytest
 
 import roaringregex_amd as rr
 from patterns import EMAIL, K1000, K1000_CONTAINS, KAT, U2, random_pattern, strings_near
-from program_replay import Dfa2Replay, DfaReplay, NfaReplay, SampledReplay
+from program_replay import Dfa2ItemsReplay, Dfa2Replay, DfaReplay, NfaReplay, SampledReplay
 from pyoracle import OracleError, OracleRegex
 
 
@@ -305,6 +305,37 @@ def test_stride2_program_keeps_the_language():
                 data = b"\n\n" + data + b"\n\n\n"
             want = list(o.match_lines(np.frombuffer(data, dtype=np.uint8))) if data else []
             assert rep.match_lines(data) == want, (p[:30], data[:60])
+
+
+def test_stride2_items_program_keeps_the_language():
+    """The stride-2 table of explicit items with separators (rrx_program_words kind 15: '\\n' an ordinary byte, code 128 the end of
+    an item) against the oracle's whole-string acceptance, item by item: items that hold '\\n', 0x00 and bytes >= 0x80, empty items,
+    ends on either code of a pair."""
+    rng = random.Random(52)
+    pats = [EMAIL, U2, "a{1,300}", K1000, "abc", "a*", ".*", "a.c", "[^a]+", "(ab|cd)+e?", "[ab]+c[ab]*"]
+    for _ in range(25):
+        p = random_pattern(rng)
+        try:
+            OracleRegex(p)
+            if rr.RRegex(p).program(rr.PROGRAM_DFA2_ITEMS) is not None:
+                pats.append(p)
+        except (OracleError, rr.RRegexError):
+            pass
+    for p in pats:
+        o = OracleRegex(p)
+        w = rr.RRegex(p).program(rr.PROGRAM_DFA2_ITEMS)
+        assert w is not None, p
+        rep = Dfa2ItemsReplay(w)
+        for trial in range(6):
+            items = []
+            for _ in range(rng.randint(0, 12)):
+                b = bytearray(random_pattern_text(rng, p).encode())
+                if b and rng.random() < 0.3:
+                    b[rng.randrange(len(b))] = rng.choice([10, 10, 0, 0x80, 0xff, 0x7f])
+                items.append(bytes(b))
+            want = [1 if (not any(c == 0 or c >= 0x80 for c in it) and o.accepts(it)) else 0 for it in items]
+            assert rep.match_items(items) == want, (p[:30], items[:6])
+    assert rr.RRegex("abc", rr.ENGINE_DFA).program(rr.PROGRAM_DFA2_ITEMS) is None       # (the byte-stride engine has no stride-2 table)
 
 
 def random_pattern_text(rng, p):
