@@ -874,7 +874,7 @@ __device__ __forceinline__ size_t ends_slot(size_t word, uint32_t sw_log2) {    
 //   ENDS = 2 (trim 0): the marked byte is the item's last byte, a byte 129 is stepped after it.
 // Bytes >= 0x80 of the text are stepped as 0x80.
 template <int ENDS>
-__global__ __launch_bounds__(kThreads) void match_items_stripes_kernel(LineDfaDevice prog, const uint8_t *__restrict__ bytes, size_t nbytes,
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void match_items_stripes_kernel(LineDfaDevice prog, const uint8_t *__restrict__ bytes, size_t nbytes,
                                                                         uint32_t stripe, const uint64_t *__restrict__ stripe_base,
                                                                         const uint32_t *__restrict__ ends, uint32_t *__restrict__ accept_bits,
                                                                         uint32_t stage_off, uint32_t stage_words,
