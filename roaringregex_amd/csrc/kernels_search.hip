@@ -246,11 +246,12 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     const size_t my_end = my + kSearchS < cend ? my + kSearchS : (my < cend ? cend : my);
     const uint32_t vlen = (uint32_t)(my_end - my);                // my bytes: kSearchS except at the end of the corpus
 
-    // ---- 1. forward pass over my bytes.  Lanes start in SKIP unless a line starts at their first byte.
-    const uint32_t last_byte = vlen ? bytes[my_end - 1] : 0u;
-    uint32_t prev_last = __shfl_up(last_byte, 1, 64);
-    const bool fresh = vlen && (lane == 0 ? chunk_fresh : prev_last == '\n');
-    uint32_t e = fresh ? t.start_e : t.skip_e;
+    // ---- 1. forward pass over my bytes.  Every lane starts as if a line started at its first byte; whether one does - the byte in
+    // front of it, the last of the lane before - is read off that lane's EVENTS afterwards, and a lane that began inside a line then
+    // drops the hits it saw before its first '\n' (what starting in SKIP gave for nothing).  (r4) Until then every lane read its
+    // last byte up front: the second cache line of its 256 bytes, touched a round before it is consumed and gone again by then -
+    // the first-match kernel fetched 1.57 x the text, FETCH_SIZE, tools/probe/traffic_check.sh.)
+    uint32_t e = vlen ? t.start_e : t.skip_e;
     constexpr int kEv = kSearchS / 16;
     uint32_t ev[kEv];                                             // 2 bits per byte, the first byte of a word highest
     {
@@ -309,6 +310,24 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
             }
         }
     }
+    const bool my_last_nl = vlen == kSearchS ? (ev[kEv - 1] & 3u) == 1u : (vlen ? bytes[my_end - 1] == '\n' : false);
+    const uint32_t prev_last_nl = __shfl_up((uint32_t)my_last_nl, 1, 64);
+    const bool fresh = vlen && (lane == 0 ? chunk_fresh : prev_last_nl != 0);
+    if (vlen && !fresh) {                                         // I began inside somebody's line: no hit of mine before my first '\n'
+        bool open = true;
+#pragma unroll
+        for (int i = 0; i < kEv; i++) {
+            if (open) {
+                const uint32_t nlm = ev[i] & ~(ev[i] >> 1) & 0x55555555u;      // fields equal to 1
+                const uint32_t hm = ev[i] & 0xaaaaaaaau, hits = hm | (hm >> 1);
+                if (nlm) {
+                    const uint32_t top = 31u - (uint32_t)__clz((int)nlm);        // low bit of the first '\n' field (the first byte is highest)
+                    ev[i] &= ~(hits & (top >= 30u ? 0u : ~0u << (top + 2u)));
+                    open = false;
+                } else ev[i] &= ~hits;
+            }
+        }
+    }
     // ---- 2. number the lines: '\n' counts, prefix over the lanes
     uint32_t nl = 0;
 #pragma unroll
@@ -321,7 +340,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
 
     // ---- 3. results.  kFirst / kCount: staged by line ordinal.  kFill: the wave's matches are the slots first[its first
     // line] ... in line order; the slot base of every staged line comes from `first`, relative to the wave's first slot.
-    const bool ends_on_nl = bytes[cend - 1] == '\n';
+    const bool ends_on_nl = cend - cstart == kSearchChunk ? __shfl((uint32_t)my_last_nl, 63, 64) != 0 : bytes[cend - 1] == '\n';
     const uint32_t lo_ord = chunk_fresh ? 0u : 1u;                // ordinals lo..hi start in this chunk: they are the wave's
     const int64_t hi_ord = ends_on_nl ? (int64_t)total_nl - 1 : (int64_t)total_nl;
     uint64_t F0 = 0;                                              // kFill: first slot of the wave
@@ -637,7 +656,7 @@ __global__ __launch_bounds__(kSearchWaves * 64) __attribute__((amdgpu_waves_per_
     }
     }
     // my last line goes on beyond my bytes and is still open (kFirst: undecided): follow it
-    int phase = (vlen == kSearchS && last_byte != '\n' && owned && !(MODE == kFirst && decided)) ? 1 : 2;   // 1: following, 2: done
+    int phase = (vlen == kSearchS && !my_last_nl && owned && !(MODE == kFirst && decided)) ? 1 : 2;   // 1: following, 2: done
     auto follow_hit = [&](uint32_t pos, uint32_t f) {
         if constexpr (MODE == kAll && COUNTING) {
 #pragma unroll
