@@ -142,7 +142,9 @@ size_t rrx_program_words(const rrx_regex *re, int kind, uint32_t *out, size_t ca
  * without '\n' is a string too.  Bytes 0x00 and >= 0x80 reject their string (the reference cannot express
  * the former and has undefined behaviour on the latter, NFA.cc:10,97).                                       */
 int    rrx_corpus_create(int device, const void *d_bytes, size_t nbytes, void *stream, rrx_corpus **out);
-/* same with an explicit stripe (bytes per GPU lane: a power of two in [1024, 16384]; 0 = chosen from nbytes) */
+/* same with an explicit stripe (bytes per GPU lane: a power of two in [512, 16384]; 0 = chosen from nbytes and the mean line length:
+ * 512 bytes up to 128 MiB - a lane steps its stripe as one chain of dependent lookups, short stripes are what makes a small corpus
+ * fast -, 2 KiB at 1 GiB, 4 KiB at 8 GiB, longer for long lines) */
 int    rrx_corpus_create_ex(int device, const void *d_bytes, size_t nbytes, uint32_t stripe_bytes, void *stream,
                             rrx_corpus **out);
 uint32_t rrx_corpus_stripe_bytes(const rrx_corpus *c);

@@ -19,8 +19,12 @@ constexpr int kThreads = RRX_THREADS;       // lanes per workgroup: one LDS copy
 // 2 KiB at 1 GiB.  Automatic choice: about two million lanes, between 2 KiB and 16 KiB; explicit: 1-16 KiB.
 constexpr uint32_t kMinStripe = 512, kMaxStripe = 16384, kMinAutoStripe = 2048;
 constexpr size_t kTargetLanes = (size_t)1 << 21;
+// (r4) Up to 512 MiB: the smallest stripe (from 512 bytes) that still leaves no more than 2^18 lanes - one generation of 256 workgroups.  A lane
+// steps its stripe pair after pair, a chain of dependent LDS lookups: a 2 KiB stripe takes 55 us however small the corpus, so with 2 KiB stripes
+// from 64 KiB to 128 MiB a match took 60-115 us on a handful of CUs; 512-byte stripes: 24-44 us (tools/probe/small_corpus_stripes.py).
 inline uint32_t pick_stripe(size_t nbytes) {
-    uint32_t s = kMinAutoStripe;
+    uint32_t s = kMinStripe;
+    while (s < kMinAutoStripe && nbytes / s > ((size_t)1 << 18)) s *= 2;
     while (s < kMaxStripe && nbytes / s > kTargetLanes) s *= 2;
     return s;
 }

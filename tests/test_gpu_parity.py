@@ -384,6 +384,39 @@ def test_long_line_variants_of_the_email_and_url_configs():
                 assert not any(o.accepts(ln[j:k]) for k in range(0, min(len(ln), 40) + 1) for j in range(0, k + 1)), (kind, ln)
 
 
+def test_indexed_match_replays_from_a_hip_graph():
+    """rrx_match_corpus is one memset and one kernel launch on the caller's stream - no host synchronisation, no allocation once the
+    tables are up - so a scan loop over several patterns can be captured in a hipGraph (torch.cuda.CUDAGraph) and replayed: the form
+    for launch-bound batches of small corpora.  Three engines (stride-2 table, byte-stride table, NFA lane engine) in one graph; the
+    replay must give what the eager calls gave, on every replay."""
+    import synth
+    dev = torch.from_numpy(synth.corpus("url", 7, 8 << 20)).cuda()
+    corpus = rr.Corpus(dev)
+    regs = [rr.RRegex(U2), rr.RRegex(EMAIL, rr.ENGINE_DFA), rr.RRegex("(a|b)*a(a|b){40}"), rr.RRegex(".*(k1|k2|k17|k100).*", rr.ENGINE_NFA)]
+    for r in regs:
+        r.set_background_order(False)                                  # (no thread of the library's own while the capture runs)
+        r.set_sampled_table(False)
+    nw = regs[0].match_corpus_bits(corpus).numel()
+    outs = [torch.zeros(nw, dtype=torch.int32, device="cuda") for _ in regs]
+    for r, o in zip(regs, outs):
+        r.match_corpus_bits(corpus, out=o)                             # eager: tables uploaded, results to compare with
+    torch.cuda.synchronize()
+    want = [o.clone() for o in outs]
+    assert int(want[0].ne(0).sum()) > 0
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.graph(graph, stream=side):
+        for r, o in zip(regs, outs):
+            r.match_corpus_bits(corpus, out=o)
+    for _ in range(3):
+        for o in outs:
+            o.fill_(-1)
+        graph.replay()
+        torch.cuda.synchronize()
+        for r, o, w in zip(regs, outs, want):
+            assert torch.equal(o, w), r.engine_name
+
+
 def test_profiled_table_order_changes_no_result():
     """At its first match against a corpus of 64 MiB or more a background thread orders the stride-2 table by a sample of the
     text (rows and columns permuted so that fewer lookups of a half-wave share an LDS bank) and swaps the tables in when it is
