@@ -103,8 +103,10 @@ int         rrx_set_option(rrx_regex *re, int option, int64_t value);
  * under (a|b)*a(a|b){40} - stays on the NFA engine at its full rate).  RRX_ERR_UNSUPPORTED: the regex is not on the NFA lane
  * engine by AUTO's choice, no table fits, or the sample escapes from it.  rrx_sampled_table: 1 = in use, 2 = being built, 0 = none,
  * 3 = RETIRED: a launch saw more than 5 % of a corpus' lines escape (every launch leaves its count in pinned host memory, the
- * next one looks at it without waiting) - the regex is back on the NFA engine for good; *table_states, *open_transitions
- * (entries that lead to ESCAPE) describe the table.  Host only.                                                            */
+ * next one looks at it without waiting) - the regex is back on the NFA engine, and the first launch against a corpus of 64 MiB
+ * or more after that LEARNS THE TABLE AGAIN from that corpus' sample (as the first build: beside the caller, or in the launch
+ * itself with RRX_OPT_BACKGROUND_ORDER 0; at most three times per regex; a new table is under the same two rules; state 1 again
+ * when it is in); *table_states, *open_transitions (entries that lead to ESCAPE) describe the table.  Host only.             */
 int         rrx_learn_table(rrx_regex *re, const void *text, size_t nbytes);
 int         rrx_sampled_table(const rrx_regex *re, uint32_t *table_states, uint32_t *open_transitions);
 /* *lines = the number of lines the NFA engine had to decide in the regex' LAST sampled-table launch on `device` (synchronous:

@@ -146,13 +146,21 @@ struct rrx_regex {
     // The same count, copied by every sampled launch into pinned host memory behind its kernels.
     // The NEXT launch looks at it without waiting (it shows the last launch that has finished): a corpus that escapes from the table
     // - not the text it was learnt from - retires the table (sampled_retired), the regex is back on the NFA engine at its own rate.
-    mutable unsigned long long *h_sampled_seen = nullptr;  // hipHostMalloc (under onepass_mu)
+    mutable unsigned long long *h_sampled_seen = nullptr;  // hipHostMalloc, one slot per table generation (under onepass_mu)
     mutable unsigned long long sampled_prev_lines = 0;     // lines of the last sampled launch queued (under onepass_mu)
     mutable std::atomic<bool> sampled_retired{false};
+    // (r4) A retired table is LEARNT AGAIN, from the sample of the corpus that retired it (the first one that carries a sample), up to
+    // kSampledRelearns times: the build runs like the first one (beside the caller unless RRX_OPT_BACKGROUND_ORDER is 0), the regex stays
+    // on the NFA engine meanwhile, and the new table is subject to the same two guards.  The old device tables are kept until rrx_free
+    // (a launch queued on them may still be running).
+    static constexpr uint32_t kSampledRelearns = 3;
+    mutable uint32_t sampled_gen = 0;                      // generation of the table in use (under onepass_mu; slot of h_sampled_seen)
+    mutable std::vector<std::unique_ptr<OnceTask>> sampled_relearn;      // (under onepass_mu)
+    mutable std::vector<std::pair<int, void *>> sampled_old_blobs;       // (under mu)
     mutable std::map<int, SampledOnDevice> sampled_on_device;
     bool sampled_eligible() const { return requested_engine == RRX_ENGINE_AUTO && engine == RRX_ENGINE_NFA && !has_dfa && has_nfa; }
     // pieces x piece_bytes of text -> the table; false: nothing usable came out (the engine stays as it is)
-    bool build_sampled(const uint8_t *text, uint32_t pieces, uint32_t piece_bytes) const {
+    bool build_sampled(const uint8_t *text, uint32_t pieces, uint32_t piece_bytes, bool replace = false) const {
         const Reduced red = reduce(trimmed);
         DfaProgram d;
         Dfa2Program d2;
@@ -167,10 +175,37 @@ struct rrx_regex {
         // text whose live sets are NOT few (random a/b lines under (a|b)*a(a|b){40}: every line escapes) would run at a fraction of
         // the plain NFA engine's rate.  More than 2 % of the sample's lines: the engine stays as it is.
         if (st.sample_escapes * 50 > st.sample_lines) return false;
+        if (replace) {
+            // no sampled launch is being queued while the programs change (onepass_mu, taken before mu as match_corpus_sampled does)
+            std::lock_guard<std::mutex> launches(onepass_mu);
+            std::lock_guard<std::mutex> lock(mu);
+            for (auto &kv : sampled_on_device) if (kv.second.blob) sampled_old_blobs.emplace_back(kv.first, kv.second.blob);
+            sampled_on_device.clear();
+            sampled_dfa = std::move(d); sampled_dfa2 = std::move(d2); sampled_stats = st;
+            sampled_gen++;                               // (its own slot of h_sampled_seen: a late count of the old table's launches does not reach it)
+            sampled_prev_lines = 0;
+            sampled_retired.store(false);
+            return true;
+        }
         std::lock_guard<std::mutex> lock(mu);
         sampled_dfa = std::move(d); sampled_dfa2 = std::move(d2); sampled_stats = st;
         sampled_ready.store(true, std::memory_order_release);
         return true;
+    }
+    // the table is retired and `c` carries a text sample: learn it again from that (once per retirement, kSampledRelearns times in all)
+    void relearn_sampled(const uint8_t *sample, uint32_t pieces, uint32_t piece_bytes) const {
+        OnceTask *task = nullptr;
+        {
+            std::lock_guard<std::mutex> launches(onepass_mu);
+            if (!sampled_retired.load() || sampled_relearn.size() >= kSampledRelearns) return;
+            if (!sampled_relearn.empty() && sampled_relearn.back()->state() != OnceTask::kDone) return;      // (one at a time)
+            sampled_relearn.emplace_back(new OnceTask());
+            task = sampled_relearn.back().get();
+        }
+        // (started outside the lock: with RRX_OPT_BACKGROUND_ORDER 0 the job runs right here, and it takes onepass_mu itself to swap the table in)
+        auto text = std::make_shared<std::vector<uint8_t>>(sample, sample + (size_t)pieces * piece_bytes);
+        (void)task->start([this, text, pieces, piece_bytes]() { (void)build_sampled(text->data(), pieces, piece_bytes, /*replace=*/true); },
+                          /*background=*/opt_background_order.load() != 0);
     }
     int sampled_tables(int device, dev::Dfa2Device *out) const {
         std::lock_guard<std::mutex> lock(mu);
@@ -355,11 +390,14 @@ struct rrx_regex {
     ~rrx_regex() {
         t2_order.wait();
         sampled_build.wait();
-        for (auto &kv : sampled_on_device) if (kv.second.blob) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.blob); }
+        for (auto &task : sampled_relearn) task->wait();
         if (h_sampled_seen) {                            // (a copy into it may still be queued on the devices that ran the sampled table)
             for (auto &kv : sampled_on_device) { (void)hipSetDevice(kv.first); (void)hipDeviceSynchronize(); }
+            for (auto &kv : sampled_old_blobs) { (void)hipSetDevice(kv.first); (void)hipDeviceSynchronize(); }
             (void)hipHostFree(h_sampled_seen);
         }
+        for (auto &kv : sampled_on_device) if (kv.second.blob) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.blob); }
+        for (auto &kv : sampled_old_blobs) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second); }
         for (auto &kv : t2_extra_blobs) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second); }
         for (auto &kv : scratch) if (kv.second.p) { (void)hipSetDevice(kv.first); (void)hipFree(kv.second.p); }
         for (auto &kv : onepass_scratch) {
@@ -1131,11 +1169,13 @@ static int match_corpus_sampled(const rrx_regex *re, const rrx_corpus *c, const 
     unsigned long long *total = reinterpret_cast<unsigned long long *>(static_cast<uint8_t *>(buf) + wide_bytes + esc_bytes);
     uint64_t *list = reinterpret_cast<uint64_t *>(static_cast<uint8_t *>(buf) + wide_bytes + esc_bytes + 16);
     re->sampled_counter[c->device] = total;
-    if (!re->h_sampled_seen && hipHostMalloc(reinterpret_cast<void **>(&re->h_sampled_seen), sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess)
-        re->h_sampled_seen[0] = 0;
-    if (re->h_sampled_seen) {
+    constexpr uint32_t kSlots = rrx_regex::kSampledRelearns + 1;
+    if (!re->h_sampled_seen && hipHostMalloc(reinterpret_cast<void **>(&re->h_sampled_seen), kSlots * sizeof(unsigned long long), hipHostMallocDefault) == hipSuccess)
+        for (uint32_t k = 0; k < kSlots; k++) re->h_sampled_seen[k] = 0;
+    unsigned long long *const seen = re->h_sampled_seen ? re->h_sampled_seen + (re->sampled_gen < kSlots ? re->sampled_gen : kSlots - 1) : nullptr;
+    if (seen) {
         // what the last FINISHED launch counted, against the size of the last launch queued (the same corpus in a scan loop; otherwise a hint)
-        const unsigned long long esc_seen = re->h_sampled_seen[0];
+        const unsigned long long esc_seen = seen[0];
         if (re->sampled_prev_lines >= 1024 && esc_seen * 20 > re->sampled_prev_lines) re->sampled_retired.store(true);   // > 5 % of the lines: the wrong table for this text
     }
     hipError_t he = hipMemsetAsync(wide, 0, wide_bytes, st);                     // (the kernel merges words with atomic OR)
@@ -1143,8 +1183,8 @@ static int match_corpus_sampled(const rrx_regex *re, const rrx_corpus *c, const 
     int e = he != hipSuccess ? (int)he : dev::match_stripes_dfa2_two_bit(d2, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, wide, stream);
     if (!e) e = dev::split_two_bit(wide, c->nlines, d_accept_bits, escaped, total, list, cap, stream);
     if (!e) e = dev::recheck_escaped_nfa(t->nfa, c->d_bytes, c->nbytes, c->stripe, c->d_base, c->nstripes, escaped, c->nlines, list, total, cap, d_accept_bits, stream);
-    if (!e && re->h_sampled_seen) {                                              // behind the kernels: the count into pinned memory (nobody waits for it)
-        if (hipMemcpyAsync(re->h_sampled_seen, total, sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess) (void)hipGetLastError();
+    if (!e && seen) {                                                            // behind the kernels: the count into pinned memory (nobody waits for it)
+        if (hipMemcpyAsync(seen, total, sizeof(unsigned long long), hipMemcpyDeviceToHost, st) != hipSuccess) (void)hipGetLastError();
         re->sampled_prev_lines = c->nlines;
     }
     const int rc2 = re->onepass_done(c->device, st);
@@ -1169,6 +1209,8 @@ int rrx_match_corpus(const rrx_regex *re, const rrx_corpus *c, uint32_t *d_accep
             (void)re->sampled_build.start([re, text, pieces]() { (void)re->build_sampled(text->data(), pieces, kSampleBytes); },
                                           /*background=*/re->opt_background_order.load() != 0);
         }
+        if (re->sampled_ready.load(std::memory_order_acquire) && re->sampled_retired.load() && c->h_sample)
+            re->relearn_sampled(c->h_sample, c->sample_lanes, kSampleBytes);     // (this launch and the next ones: the NFA engine, until the new table is in)
         if (re->sampled_ready.load(std::memory_order_acquire) && !re->sampled_retired.load()) return match_corpus_sampled(re, c, t, d_accept_bits, stream);
     }
     // the kernel merges words with atomic OR: start from an all-zero bitmap

@@ -582,6 +582,55 @@ def test_sampled_table_learnt_from_the_first_large_corpus():
         assert torch.equal(r.match_corpus_bits(corpus), ref)
 
 
+def test_sampled_table_is_learnt_again_from_the_corpus_that_retired_it():
+    """A table learnt from bare URLs (scheme, host, nothing else), then the URL corpus proper - ports, paths, queries the old table has
+    never seen: most lines escape, the table is retired.  The first launch against that corpus after the retirement starts a new build
+    from the corpus' own sample; launches race the swap and are exact throughout (the NFA engine while the table is out: equal to a regex
+    that never had one, and to the oracle on the head of the corpus); afterwards next to no line escapes, and the bare URLs run on the
+    new table too."""
+    import synth
+    import time
+    pattern = U2 + "(x|y)*x(x|y){30}"
+    url = synth.corpus("url", 9, 72 << 20)                             # (large enough to carry a text sample)
+    rng = random.Random(5)
+    bare = np.frombuffer(b"".join(rng.choice([b"http", b"https", b"ftp"]) + b"://" + bytes(rng.choice(b"abcdefghij") for _ in range(rng.randint(2, 9))) +
+                                  b"." + rng.choice([b"com", b"org", b"de"]) + rng.choice([b"", b"", b"", b" "]) + b"\n" for _ in range(40000)), dtype=np.uint8)
+    dev_a, dev_b = torch.from_numpy(bare.copy()).cuda(), torch.from_numpy(url).cuda()
+    corpus_a, corpus_b = rr.Corpus(dev_a), rr.Corpus(dev_b)
+    plain = rr.RRegex(pattern)
+    plain.set_sampled_table(False)
+    ref_a, ref_b = plain.match_corpus_bits(corpus_a).clone(), plain.match_corpus_bits(corpus_b).clone()
+    head = url[:1 << 19]
+    cut = int(np.flatnonzero(head == 10)[-1]) + 1
+    o = OracleRegex(pattern)
+    want = o.match_lines(head[:cut])
+    got = plain.match_corpus(corpus_b).cpu().numpy()
+    assert (got[:len(want)] == want).all()
+    assert (plain.match_corpus(corpus_a).cpu().numpy() == o.match_lines(bare)).all()
+    for background in (True, False):                                   # (False: the new build runs inside the launch that starts it)
+        r = rr.RRegex(pattern)
+        r.set_background_order(background)
+        first = r.learn_table(bare[:1 << 16])
+        assert torch.equal(r.match_corpus_bits(corpus_a), ref_a) and r.sampled_escapes() < corpus_a.num_lines // 50
+        assert torch.equal(r.match_corpus_bits(corpus_b), ref_b)          # on the old table: ports, paths and queries escape
+        assert r.sampled_escapes() > corpus_b.num_lines // 20             # (more than the 5 % that retire a table)
+        torch.cuda.synchronize()
+        assert torch.equal(r.match_corpus_bits(corpus_b), ref_b)          # the launch that sees that count: retired
+        assert r.sampled_table_retired
+        t0 = time.time()
+        launches = 0
+        while r.sampled_table_retired and time.time() - t0 < 60:           # the launches that start the new build and race it
+            assert torch.equal(r.match_corpus_bits(corpus_b), ref_b)
+            launches += 1
+        assert not r.sampled_table_retired and r.sampled_table is not None and r.sampled_table != first, (launches, r.sampled_table, first)
+        for _ in range(3):
+            assert torch.equal(r.match_corpus_bits(corpus_b), ref_b)
+        assert r.sampled_escapes() < corpus_b.num_lines // 50
+        assert torch.equal(r.match_corpus_bits(corpus_a), ref_a) and r.sampled_escapes() < corpus_a.num_lines // 50
+        torch.cuda.synchronize()
+        assert torch.equal(r.match_corpus_bits(corpus_a), ref_a) and not r.sampled_table_retired
+
+
 def test_sampled_table_is_not_installed_where_the_text_escapes_from_it():
     """(a|b)*a(a|b){40} over random a/b lines: every line reaches a set no sample has shown, a sampled table would send every line
     through the NFA engine a second time.  The build (started by the first launch against a large corpus) must find that on its own
