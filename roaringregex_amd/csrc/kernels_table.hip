@@ -310,7 +310,7 @@ __device__ __forceinline__ void dfa2_stripe(const Dfa2 &eng, const size_t g, con
                                             const uint8_t *__restrict__ bytes, const size_t nbytes, const uint32_t stripe,
                                             const uint64_t *__restrict__ stripe_base, uint32_t *__restrict__ accept_bits,
                                             uint32_t *__restrict__ counts, uint32_t *__restrict__ slabs, const uint32_t slab_row, PhaseHook &phase,
-                                            const uint32_t flush_mask = 31u) {
+                                            const uint32_t flush_word = 31u) {
     const size_t start = g * (size_t)stripe;
     if (start < nbytes) {                                            // (no early return: the write-out below is collective)
     const size_t stripe_end = start + stripe;
@@ -346,7 +346,12 @@ __device__ __forceinline__ void dfa2_stripe(const Dfa2 &eng, const size_t g, con
     // L2 round trips at the end of every wave's life, and the waves of a workgroup - of the whole chip, launched together
     // and fed at the same rate - reach that point at the same time.
     uint32_t last_word = 0;                                       // the last text word of my stripe (whole rounds only)
-    bool ahead = false;                                           // buf holds the 128 bytes behind my stripe
+    bool ahead = false;                                           // buf holds the first bytes behind my stripe
+    // (r4) ... the first `ahead_slots` x 16 of them (bits 8-11 of the flush word; 0 = all eight): those 128 bytes are the first cache line of
+    // the NEXT lane's stripe, long gone from the caches - 12.5 % more fetched bytes on 1-KiB stripes (5-byte lines: FETCH_SIZE 1.146 x
+    // the text) for a line that ends a few bytes on.  The host asks for one slot on corpora of very short lines (flush_mask_for).
+    const uint32_t flush_mask = flush_word & 0xffu;
+    const uint32_t ahead_slots = __builtin_amdgcn_readfirstlane((flush_word >> 8) & 15u) ? __builtin_amdgcn_readfirstlane((flush_word >> 8) & 15u) : 8u;
     for (int r = 0; r < rounds; r++) {
         if (r == 1) phase(kPhaseFirstRound);
         phase.round(r);
@@ -377,7 +382,12 @@ __device__ __forceinline__ void dfa2_stripe(const Dfa2 &eng, const size_t g, con
         } else {
             last_word = buf[kSlots - 1].w;
             if (start + (size_t)(rounds + 1) * kRound <= nbytes) {
-                feed_load<FEED_ASM>(buf, src + (r + 1) * kSlots);
+                if (FEED_ASM || ahead_slots == 8u) feed_load<FEED_ASM>(buf, src + (r + 1) * kSlots);
+                else {
+#pragma unroll
+                    for (int i = 0; i < kSlots; i++)
+                        if ((uint32_t)i < ahead_slots) buf[i] = load_text(src + (r + 1) * kSlots + i);
+                }
                 ahead = true;
             }
         }
@@ -419,7 +429,7 @@ __device__ __forceinline__ void dfa2_stripe(const Dfa2 &eng, const size_t g, con
         if (ahead && pos == start + (size_t)(rounds + 1) * kRound - kRound) {      // (pos == my_end: the requested bytes are the next ones)
     #pragma unroll
             for (int i = 0; i < kSlots; i++) {
-                if (!lines) {
+                if (!lines && (FEED_ASM || (uint32_t)i < ahead_slots)) {
                     const uint32_t w[4] = {clean(buf[i].x), clean(buf[i].y), clean(buf[i].z), clean(buf[i].w)};
 #pragma unroll
                     for (int k = 0; k < 8; k++)
@@ -1428,7 +1438,11 @@ uint32_t flush_mask_for(size_t nbytes, size_t nlines) {
     const size_t avg = nlines ? nbytes / nlines : nbytes;
     uint32_t slots = 1;
     while (slots < 32 && (size_t)slots * 2 * 16 <= avg * 16) slots *= 2;      // (measured: profiles/r04_flush_period_ab.txt)
-    return slots - 1;
+    // bits 8-11: the 16-byte slots a lane requests ahead behind its stripe (its straddling line): ONE where two mean line lengths fit into it, else
+    // all eight (tools/probe/ahead_ab.py: 5-byte lines on 1-KiB stripes +3.3 %; three slots on the email corpus, six on the URL corpus: 0 / -1.2 %
+    // - the requests no longer form one burst and longer lines finish 16 bytes at a time)
+    const uint32_t ahead = 2 * avg <= 16 ? 1u : 8u;
+    return (slots - 1) | ahead << 8;
 }
 int match_stripes_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
                        size_t nstripes, uint32_t *accept, void *stream, uint32_t flush_mask) {
