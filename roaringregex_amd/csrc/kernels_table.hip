@@ -305,16 +305,12 @@ __device__ __forceinline__ void feed_load(uint4 (&buf)[kRound / 16], const uint4
 // One stripe of one lane: lane-local state only (what the caller keeps across stripes is the engine, the window and `g`).
 // KB: result bits per line - 1 (accepted), or 2 (accepted, ESCAPED: the sampled-table engine, whose table does not know every
 // transition; the table's line ends then shift two bits in, and everything that counts results counts bits).
-// NEIGHBOUR (corpora of very short lines: 1-KiB stripes): the bytes behind my stripe are the first of the NEXT lane's stripe - a cache line that lane
-// read in its first round and that has left the caches by my last one: fetching it again was 12.5 % more fetched bytes on 1-KiB stripes
-// (profiles/r04_ahead_bytes_ab.txt).  Every lane keeps its own first eight bytes in two registers and hands them to the lane before it with a
-// cross-lane shift when the stripes are done; only the wave's last lane asks memory, and a line that goes on past those eight bytes.
-template <bool ONEPASS, class PhaseHook, bool FEED_ASM = false, int KB = 1, bool NEIGHBOUR = false>
+template <bool ONEPASS, class PhaseHook, bool FEED_ASM = false, int KB = 1>
 __device__ __forceinline__ void dfa2_stripe(const Dfa2 &eng, const size_t g, const uint64_t window_word, uint32_t *const stage, const uint32_t stage_words,
                                             const uint8_t *__restrict__ bytes, const size_t nbytes, const uint32_t stripe,
                                             const uint64_t *__restrict__ stripe_base, uint32_t *__restrict__ accept_bits,
                                             uint32_t *__restrict__ counts, uint32_t *__restrict__ slabs, const uint32_t slab_row, PhaseHook &phase,
-                                            const uint32_t flush_word = 31u) {
+                                            const uint32_t flush_mask = 31u) {
     const size_t start = g * (size_t)stripe;
     if (start < nbytes) {                                            // (no early return: the write-out below is collective)
     const size_t stripe_end = start + stripe;
@@ -345,20 +341,12 @@ __device__ __forceinline__ void dfa2_stripe(const Dfa2 &eng, const size_t g, con
     const int rounds = (int)((my_end - start) / kRound);
     uint4 buf[kSlots];
     if (rounds > 0) feed_load<FEED_ASM>(buf, src);
-    uint32_t head0 = 0, head1 = 0;                                // NEIGHBOUR: my first eight bytes
-    if (NEIGHBOUR && rounds > 0) { head0 = buf[0].x; head1 = buf[0].y; }
-    const bool wave_last = ((uint32_t)g & 63u) == 63u;
     // The line that straddles my stripe end is followed into the next stripe's text (below).  Its first 128 bytes are
     // requested while the last round is still being stepped: loaded on demand, 16 bytes at a time, they were a chain of
     // L2 round trips at the end of every wave's life, and the waves of a workgroup - of the whole chip, launched together
     // and fed at the same rate - reach that point at the same time.
     uint32_t last_word = 0;                                       // the last text word of my stripe (whole rounds only)
-    bool ahead = false;                                           // buf holds the first bytes behind my stripe
-    // (r4) ... the first `ahead_slots` x 16 of them (bits 8-11 of the flush word; 0 = all eight): those 128 bytes are the first cache line of
-    // the NEXT lane's stripe, long gone from the caches - 12.5 % more fetched bytes on 1-KiB stripes (5-byte lines: FETCH_SIZE 1.146 x
-    // the text) for a line that ends a few bytes on.  The host asks for one slot on corpora of very short lines (flush_mask_for).
-    const uint32_t flush_mask = flush_word & 0xffu;
-    const uint32_t ahead_slots = __builtin_amdgcn_readfirstlane((flush_word >> 8) & 15u) ? __builtin_amdgcn_readfirstlane((flush_word >> 8) & 15u) : 8u;
+    bool ahead = false;                                           // buf holds the 128 bytes behind my stripe
     for (int r = 0; r < rounds; r++) {
         if (r == 1) phase(kPhaseFirstRound);
         phase.round(r);
@@ -388,23 +376,14 @@ __device__ __forceinline__ void dfa2_stripe(const Dfa2 &eng, const size_t g, con
             feed_load<FEED_ASM>(buf, src + (r + 1) * kSlots);
         } else {
             last_word = buf[kSlots - 1].w;
-            if (NEIGHBOUR) {
-                if (wave_last && start + (size_t)(rounds + 1) * kRound <= nbytes) { buf[0] = load_text(src + (r + 1) * kSlots); ahead = true; }
-            } else if (start + (size_t)(rounds + 1) * kRound <= nbytes) {
-                if (FEED_ASM || ahead_slots == 8u) feed_load<FEED_ASM>(buf, src + (r + 1) * kSlots);
-                else {
-#pragma unroll
-                    for (int i = 0; i < kSlots; i++)
-                        if ((uint32_t)i < ahead_slots) buf[i] = load_text(src + (r + 1) * kSlots + i);
-                }
+            if (start + (size_t)(rounds + 1) * kRound <= nbytes) {
+                feed_load<FEED_ASM>(buf, src + (r + 1) * kSlots);
                 ahead = true;
             }
         }
     }
     pos += (size_t)rounds * kRound;
     phase(kPhaseMainDone);
-    uint32_t next0 = 0, next1 = 0;                                // NEIGHBOUR: the first eight bytes of the stripe behind mine
-    if constexpr (NEIGHBOUR) { next0 = __shfl_down(head0, 1, 64); next1 = __shfl_down(head1, 1, 64); }       // (every lane with a stripe is here)
     auto byte_at = [&](size_t q) -> uint32_t { const uint32_t b = bytes[q]; return (ONEPASS && b >= 0x80u) ? 0u : b; };
 
     // ---- tail of the corpus inside my stripe (only the last stripe has one): whole pairs, then an odd last byte.
@@ -437,18 +416,10 @@ __device__ __forceinline__ void dfa2_stripe(const Dfa2 &eng, const size_t g, con
     const uint32_t last_byte = whole_rounds ? last_word >> 24 : (uint32_t)bytes[my_end - 1];
     if (!closed_by_end_of_data && started && last_byte != '\n') {
         uint32_t lines = 0, verdicts = 0;
-        if (NEIGHBOUR && !wave_last && whole_rounds && pos == my_end && my_end + kRound <= nbytes) {     // (the next lane has a whole round: its head is set)
-            const uint32_t w[2] = {clean(next0), clean(next1)};
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (!lines) eng.step2(st, (w[k >> 1] >> (16 * (k & 1))) & 0xffu, (w[k >> 1] >> (16 * (k & 1) + 8)) & 0xffu, lines, verdicts);
-            pos += 8;
-            for (; !lines && (pos & 15) && pos + 2 <= nbytes; pos += 2) eng.step2(st, byte_at(pos), byte_at(pos + 1), lines, verdicts);     // (rare: a longer line)
-        } else
         if (ahead && pos == start + (size_t)(rounds + 1) * kRound - kRound) {      // (pos == my_end: the requested bytes are the next ones)
     #pragma unroll
             for (int i = 0; i < kSlots; i++) {
-                if (!lines && (FEED_ASM || (uint32_t)i < (NEIGHBOUR ? 1u : ahead_slots))) {
+                if (!lines) {
                     const uint32_t w[4] = {clean(buf[i].x), clean(buf[i].y), clean(buf[i].z), clean(buf[i].w)};
 #pragma unroll
                     for (int k = 0; k < 8; k++)
@@ -477,7 +448,7 @@ __device__ __forceinline__ void dfa2_stripe(const Dfa2 &eng, const size_t g, con
     }
 }
 
-template <bool ONEPASS, class PhaseHook = NoPhaseHook, int KB = 1, bool NEIGHBOUR = false>
+template <bool ONEPASS, class PhaseHook = NoPhaseHook, int KB = 1>
 __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t *__restrict__ bytes, size_t nbytes, uint32_t stripe,
                                           const uint64_t *__restrict__ stripe_base, uint32_t *__restrict__ accept_bits,
                                           uint32_t *__restrict__ counts, uint32_t *__restrict__ slabs, PhaseHook phase = PhaseHook(),
@@ -502,7 +473,7 @@ __device__ __forceinline__ void dfa2_body(const Dfa2Device &prog, const uint8_t 
     const size_t g0 = (size_t)blockIdx.x * kThreads;
     uint64_t window_word = 0;
     if (!ONEPASS) window_word = (line_of(stripe_base[g0]) * KB) >> 5;       // the workgroup's first stripe exists: uniform load
-    dfa2_stripe<ONEPASS, PhaseHook, false, KB, NEIGHBOUR>(eng, g0 + threadIdx.x, window_word, stage, stage_words, bytes, nbytes, stripe, stripe_base, accept_bits, counts, slabs,
+    dfa2_stripe<ONEPASS, PhaseHook, false, KB>(eng, g0 + threadIdx.x, window_word, stage, stage_words, bytes, nbytes, stripe, stripe_base, accept_bits, counts, slabs,
                          gridDim.x * kThreads, phase, flush_mask);
     if (!ONEPASS) {
         // ---- write the window out: consecutive lanes, consecutive words (the atomics merge into whole lines in L2;
@@ -580,12 +551,6 @@ __global__ __launch_bounds__(kThreads) void match_stripes2_kernel(Dfa2Device pro
     dfa2_body<false>(prog, bytes, nbytes, stripe, stripe_base, accept_bits, nullptr, nullptr, NoPhaseHook(), flush_mask);
 }
 // two result bits per line (accepted, escaped) into a bitmap of twice the size: the sampled-table engine's first pass
-// (the NEIGHBOUR build: corpora whose mean line is eight bytes or less - bit 12 of the flush word)
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(8, 8))) void match_stripes2_short_lines_kernel(
-    Dfa2Device prog, const uint8_t *__restrict__ bytes, size_t nbytes, uint32_t stripe, const uint64_t *__restrict__ stripe_base,
-    uint32_t *__restrict__ accept_bits, uint32_t flush_mask) {
-    dfa2_body<false, NoPhaseHook, 1, true>(prog, bytes, nbytes, stripe, stripe_base, accept_bits, nullptr, nullptr, NoPhaseHook(), flush_mask);
-}
 __global__ __launch_bounds__(kThreads) void match_stripes2_two_bit_kernel(Dfa2Device prog, const uint8_t *__restrict__ bytes, size_t nbytes,
                                                                            uint32_t stripe, const uint64_t *__restrict__ stripe_base,
                                                                            uint32_t *__restrict__ wide_bits) {
@@ -1459,26 +1424,18 @@ int match_stripes_dfa(const LineDfaDevice &p, bool clamp_high, const uint8_t *by
 #undef GO
 }
 // slots (16 bytes of a lane's text) between two flushes of ALL lanes, minus one: about sixteen line ends per period
-constexpr uint32_t kFlushShortLines = 1u << 12;      // flush word: the kernel build whose lanes hand their first bytes to the lane before them
 uint32_t flush_mask_for(size_t nbytes, size_t nlines) {
     const size_t avg = nlines ? nbytes / nlines : nbytes;
     uint32_t slots = 1;
     while (slots < 32 && (size_t)slots * 2 * 16 <= avg * 16) slots *= 2;      // (measured: profiles/r04_flush_period_ab.txt)
-    // bits 8-11: the 16-byte slots a lane requests ahead behind its stripe (its straddling line): ONE where two mean line lengths fit into it, else
-    // all eight (tools/probe/ahead_ab.py: 5-byte lines on 1-KiB stripes +3.3 %; three slots on the email corpus, six on the URL corpus: 0 / -1.2 %
-    // - the requests no longer form one burst and longer lines finish 16 bytes at a time)
-    const uint32_t ahead = 2 * avg <= 16 ? 1u : 8u;
-    return (slots - 1) | ahead << 8 | (2 * avg <= 16 ? kFlushShortLines : 0u);
+    return slots - 1;
 }
 int match_stripes_dfa2(const Dfa2Device &p, const uint8_t *bytes, size_t nbytes, uint32_t stripe, const uint64_t *stripe_base,
                        size_t nstripes, uint32_t *accept, void *stream, uint32_t flush_mask) {
     if (!nstripes) return 0;
     if (Dfa2::lds_bytes(p) > kDfa2MaxTable) return (int)hipErrorInvalidValue;
     size_t blocks = (nstripes + kThreads - 1) / kThreads;
-    if (flush_mask & kFlushShortLines)
-        hipLaunchKernelGGL(match_stripes2_short_lines_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept, flush_mask);
-    else
-        hipLaunchKernelGGL(match_stripes2_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept, flush_mask);
+    hipLaunchKernelGGL(match_stripes2_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, (hipStream_t)stream, p, bytes, nbytes, stripe, stripe_base, accept, flush_mask);
     return (int)hipGetLastError();
 }
 // ---- the sampled-table engine's second step: the two-bit bitmap (bit 2i = line i accepted, bit 2i + 1 = line i ended in the

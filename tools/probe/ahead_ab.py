@@ -1,5 +1,6 @@
-"""The bytes a lane requests behind its stripe for its straddling line: automatic (about two mean line lengths: bits 8-11 of the flush word) against all 128
-(an explicit flush period of the same length leaves those bits 0 = eight slots).  Same process, alternating; kernel time by events.
+"""A/B harness of profiles/r04_ahead_bytes_ab.txt: the automatic flush word against an explicit flush period of the same length, same process, alternating.  While the
+experiments of that file were in the tree the two took different paths of the stride-2 kernel (bytes requested behind the stripe; the build for very short lines); in the
+shipping tree both are the same kernel, so this now shows the noise of such a comparison.  Run it from a second checkout to compare builds (tools/probe/ab_oldtree.sh).
 usage: ahead_ab.py [workload ...]"""
 import os, sys, time
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
