@@ -384,6 +384,25 @@ def test_long_line_variants_of_the_email_and_url_configs():
                 assert not any(o.accepts(ln[j:k]) for k in range(0, min(len(ln), 40) + 1) for j in range(0, k + 1)), (kind, ln)
 
 
+def test_small_corpora_take_short_stripes():
+    """The automatic stripe: 512 bytes while the corpus leaves no more than 2^18 lanes (a lane steps its stripe as one chain of dependent
+    lookups: short stripes are what makes a small corpus fast), 2 KiB at 1 GiB as before; the stripe never changes a result."""
+    import synth
+    for nbytes, want_stripe in ((64 << 10, 512), (16 << 20, 512), (128 << 20, 512), (256 << 20, 1024)):
+        host = synth.corpus("url", 13, nbytes)
+        dev = torch.from_numpy(host).cuda()
+        auto = rr.Corpus(dev)
+        assert auto.stripe == want_stripe, (nbytes, auto.stripe)
+        r = rr.RRegex(U2)
+        got = r.match_corpus_bits(auto)
+        assert torch.equal(got, r.match_corpus_bits(rr.Corpus(dev, stripe=4096)))
+        head = host[:1 << 18]
+        cut = int(np.flatnonzero(head == 10)[-1]) + 1
+        want = OracleRegex(U2).match_lines(head[:cut])
+        assert (_bits_to_bytes(got, len(want)) == want).all()
+        del dev, auto
+
+
 def test_indexed_match_replays_from_a_hip_graph():
     """rrx_match_corpus is one memset and one kernel launch on the caller's stream - no host synchronisation, no allocation once the
     tables are up - so a scan loop over several patterns can be captured in a hipGraph (torch.cuda.CUDAGraph) and replayed: the form
