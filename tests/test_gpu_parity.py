@@ -1375,6 +1375,25 @@ def test_explicit_items_stripe_wise():
     off = torch.cat([torch.zeros(1, dtype=torch.int64, device="cuda"), nl + 1]).contiguous()
     r = rr.RRegex("[^@]*")
     assert torch.equal(r.match_extents(dev, off, trim=0), pieces(r, dev, off, 0))
+    # ... and with a separator behind every item (trim 1: the stride-2 items table, in which '\n' is a byte like any other and only
+    # the marked byte ends an item): ';' as the separator, real '\n' bytes inside some items - accepted by this pattern
+    h2 = host.copy(); h2[h2 == 10] = ord(";")
+    inside = np.nonzero(h2 != ord(";"))[0][::50021]
+    h2[inside] = 10
+    d2 = torch.from_numpy(h2).cuda()
+    for pat in ("[^@]*", ".*", "[^;]*"):
+        rp = rr.RRegex(pat)
+        got = rp.match_extents(d2, off, trim=1)
+        assert torch.equal(got, pieces(rp, d2, off, 1)), pat
+        assert torch.equal(rp.match_items(rr.Items(d2, off, trim=1)), got), pat
+        rp.set_items_stride2(False)                                     # the byte-stride items kernel on the same batch
+        assert torch.equal(rp.match_extents(d2, off, trim=1), got), pat
+    o = OracleRegex("[^@]*")
+    got = rr.RRegex("[^@]*").match_extents(d2, off, trim=1).cpu().numpy()
+    offs = off.cpu().numpy()
+    for i in list(range(0, 2000)) + [int(np.searchsorted(offs, p, side="right")) - 1 for p in inside[:50]]:
+        item = h2[offs[i]:offs[i + 1] - 1].tobytes()
+        assert got[i] == (1 if o.accepts(item) else 0), (i, item)
 
 
 def test_explicit_items_inside_a_far_larger_allocation():
